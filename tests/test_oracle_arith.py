@@ -1,0 +1,118 @@
+"""Arithmetic on the counts: MinorAlleleFrequency, computeMarginalInformation,
+the build-defined chi-square / HWE statistics and the pairwise LLR KATs.
+CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_minor_allele_frequency_quirk(oracle):
+    # algorithms/maf_func.h:46-54: (2aa+ab)/tot, flipped below 0.5 (quirk Q5)
+    tot, maf = oracle.minor_allele_frequency((10, 20, 70, 5))
+    assert tot == 100.0 and maf == pytest.approx(1.0 - 0.4)
+    tot, maf = oracle.minor_allele_frequency((70, 20, 10, 0))
+    assert maf == pytest.approx(1.6)  # not a frequency: the reference divides by tot, not 2*tot
+    tot, maf = oracle.minor_allele_frequency((25, 0, 75, 0))
+    assert maf == 0.5
+
+
+def test_marginal_information(oracle):
+    cases, ctrls = (30, 50, 20, 3), (40, 45, 10, 2)
+    n = sum(cases) + sum(ctrls)
+    m = oracle.marginal_information(cases, ctrls, n)
+    mar = [a + b for a, b in zip(cases, ctrls)]
+    assert (m.margins.aa, m.margins.ab, m.margins.bb, m.margins.xx) == tuple(mar)
+    h = -sum(v / n * math.log(v / n) for v in mar if v)
+    hy = -sum(v / n * math.log(v / n) for v in cases + ctrls if v)
+    assert m.marginal_entropy == pytest.approx(h, rel=1e-14)
+    assert m.marginal_entropy_y == pytest.approx(hy, rel=1e-14)
+    for i in range(4):
+        assert m.pbc[i] == cases[i] / sum(cases)
+        assert m.pbc[4 + i] == ctrls[i] / sum(ctrls)
+        assert m.pca[i] == cases[i] / mar[i]
+        assert m.pca[4 + i] == ctrls[i] / mar[i]
+    with pytest.raises(ValueError):
+        oracle.marginal_information(cases, ctrls, n + 1)  # common_genotype_func.cpp:180 assert
+
+
+def test_assoc_stats_against_scipy(oracle):
+    """The chi-square / HWE definitions are the build's own (the reference has
+    none: SURVEY.md 8a row 13) -- cross-checked here against scipy's Pearson
+    chi-square so that the definition itself is the textbook one."""
+    from scipy.stats import chi2_contingency
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        ca = tuple(int(v) for v in rng.integers(1, 5000, size=3)) + (int(rng.integers(0, 50)),)
+        co = tuple(int(v) for v in rng.integers(1, 5000, size=3)) + (int(rng.integers(0, 50)),)
+        s = oracle.assoc_stats(ca, co)
+        geno = chi2_contingency(np.array([ca[:3], co[:3]]), correction=False)[0]
+        alle = chi2_contingency(np.array([[2 * ca[0] + ca[1], 2 * ca[2] + ca[1]],
+                                          [2 * co[0] + co[1], 2 * co[2] + co[1]]]), correction=False)[0]
+        assert s[5] == pytest.approx(geno, rel=1e-11)
+        assert s[6] == pytest.approx(alle, rel=1e-11)
+        for k, (aa, ab, bb) in ((3, co[:3]), (4, tuple(a + b for a, b in zip(ca[:3], co[:3])))):
+            nn = aa + ab + bb
+            p = (2 * aa + ab) / (2 * nn)
+            e = (nn * p * p, 2 * nn * p * (1 - p), nn * (1 - p) ** 2)
+            assert s[k] == pytest.approx(sum((o - x) ** 2 / x for o, x in zip((aa, ab, bb), e)), rel=1e-11)
+        assert s[0] == oracle.minor_allele_frequency(ca)[1]
+        assert s[1] == oracle.minor_allele_frequency(co)[1]
+        p = (2 * (ca[0] + co[0]) + ca[1] + co[1]) / (2 * (sum(ca[:3]) + sum(co[:3])))
+        assert s[2] == pytest.approx(min(p, 1 - p), rel=1e-15)
+        assert s[7] == pytest.approx((sum(ca[:3]) + sum(co[:3])) / (sum(ca) + sum(co)), rel=1e-15)
+
+
+def test_assoc_stats_degenerate(oracle):
+    z = oracle.assoc_stats((0, 0, 0, 0), (0, 0, 0, 0))
+    assert np.all(z == 0) and np.all(np.isfinite(z))
+    s = oracle.assoc_stats((10, 0, 0, 0), (7, 0, 0, 1))  # monomorphic
+    assert np.all(np.isfinite(s)) and s[5] == 0 and s[6] == 0 and s[3] == 0
+    s = oracle.assoc_stats((0, 0, 0, 5), (3, 4, 5, 0))  # no called cases
+    assert np.all(np.isfinite(s)) and s[0] == 0 and s[5] == 0
+
+
+# src/test/pairwise.c:20-37: the five literal case/control 3x3 tables.  The
+# file stores no expected output; the values below are the ones SURVEY.md
+# section 4 records for them ("[probed]", produced during the survey from the
+# reference's own pairwise_epi_test).
+PAIRWISE_KAT = [
+    ("boost0", [[5, 24, 14], [57, 138, 96], [151, 315, 187]],
+     [[4, 16, 10], [71, 176, 86], [120, 330, 200]], 5.6412445164852567),
+    ("boost1", [[227, 225, 29], [191, 189, 58], [24, 33, 11]],
+     [[229, 219, 67], [195, 199, 26], [33, 42, 3]], 33.381542422601164),
+    ("boost2", [[32, 103, 93], [49, 250, 203], [52, 94, 111]],
+     [[33, 121, 96], [76, 203, 227], [20, 124, 113]], 30.715608133058666),
+    ("biforce1", [[2, 10, 12], [31, 130, 87], [75, 295, 345]],
+     [[3, 14, 3], [16, 90, 143], [84, 353, 307]], 39.162377641819205),
+    ("biforce2", [[21, 214, 289], [7, 119, 260], [0, 0, 77]],
+     [[12, 123, 542], [3, 69, 223], [4, 14, 23]], 80.980275431820317),
+]
+
+
+@pytest.mark.parametrize("name,cs,ct,llr", PAIRWISE_KAT)
+def test_pairwise_llr_kat(oracle, name, cs, ct, llr):
+    assert oracle.pairwise_llr(cs, ct) == pytest.approx(llr, rel=1e-12)
+
+
+def test_simulator_shape(oracle):
+    """Restated simulate_data.cpp: p = bin/100 + U{0..999}/1e5 with the bin
+    drawn from the affy6 spectrum; genotypes in HWE; coin-flip phenotype."""
+    seed = 0x5EED
+    ps = np.array([oracle.sim_snp_p_e5(seed, s) for s in range(4000)]) / 1e5
+    assert ps.min() >= 0 and ps.max() < 0.51
+    assert 0.18 < ps.mean() < 0.30  # affy6 spectrum mean is ~0.236
+    n = 20_000
+    table, g = oracle.sim_table_stream(seed, 100, 8, n)
+    cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+    assert nc + nt == n and abs(nc - n / 2) < 4 * (n ** 0.5)
+    for r in range(8):
+        aa, ab, bb, xx = oracle.stream_dist(table[r], g)
+        assert aa + ab + bb == n  # no missing by default
+        p = oracle.sim_snp_p_e5(seed, 100 + r) / 1e5
+        q = (ab + 2 * bb) / (2 * n)
+        assert abs(q - p) < 5 * (p * (1 - p) / (2 * n)) ** 0.5 + 2e-5
+    t2, _ = oracle.sim_table_stream(seed, 100, 2, n, missing_q16=655)  # ~1 %
+    aa, ab, bb, xx = oracle.stream_dist(t2[0], g)
+    miss = n - (aa + ab + bb)
+    assert 100 < miss < 320
