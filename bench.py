@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- SNPs/s of the per-SNP case/control association scan on MI355X.
+
+A "step" is one pass of the hot path (fused counts + MAF + HWE + chi-square
+kernel, one launch) over the rank's whole genotype table, inputs resident in
+HBM.  Default workload = BASELINE.json configs[2] ("c3"): 500 000 samples x
+1 000 000 SNPs (125 GB of 2-bit genotypes) on one GPU -- the configuration the
+north-star target (>= 70 % of the HBM-read roofline) is quoted on.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU.  SNP rows shard by contiguous ranges (weak scaling: every
+rank scans its own full-size shard, global SNP index = rank * M + row), and the
+one exchange step of the path -- the gather of per-SNP statistics to rank 0
+over RCCL/xGMI -- runs chunk-wise on RCCL's stream under the next chunk's scan.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = SNPs all ranks
+processed / max-over-ranks wall time; "roofline" for the scan kernel from HIP
+events on the launching stream; "cpu_baseline" = the CPU oracle's faithful
+single-thread port timed on this host on a bounded sample of the same table.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_samples, n_snps per GPU, text)
+    "c1": (10_000, 50_000, "c1: 10k samples x 50k SNPs case/control chi2 scan (plumbing size)"),
+    "c2": (100_000, 500_000, "c2: 100k samples x 500k SNPs, per-SNP 3x3 contingency + chi2"),
+    "c3": (500_000, 1_000_000, "c3: 500k samples x 1M SNPs, MAF + HWE + case/control chi2 combined scan"),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 0x5EED
+RECORD_BYTES = 32 + 64  # counts uint32[8] + stats float64[8] per SNP
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--snps", type=int, default=0, help="override SNPs per GPU (debug)")
+    ap.add_argument("--chunks", type=int, default=4, help="scan/gather pipeline chunks when N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
+    ap.add_argument("--unroll", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--mask-lds", type=int, default=-1)
+    ap.add_argument("--nt", type=int, default=-1)
+    return ap.parse_args()
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass, or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(table, n_samples, seconds):
+    """The oracle's faithful port of the reference CPU path (one thread, 64 Ki
+    LUT popcount, the word loop of compressed_genotype_table5.cpp:609-657),
+    timed on this host on the first rows of the SAME synthetic table, plus a
+    parity check of the GPU results on that sample."""
+    import numpy as np
+    from oracle import oracle  # the reported baseline / checker -- never the measured path
+
+    g = oracle.geometry_stream(n_samples)
+    bytes_per_snp = n_samples / 4.0
+    # ~1 GB/s per core for the faithful port: size the sample for `seconds` of work in 3 passes
+    sample = int(max(256, min(table.n_snps, (seconds / 3.0) * 1.0e9 / bytes_per_snp)))
+    rows = table.download_rows(0, sample)
+    cs, ct, nc, nt = table.get_case_control()
+    t0 = time.perf_counter()
+    passes, counts, stats = 0, None, None
+    while passes < 2 or time.perf_counter() - t0 < seconds * 0.8:
+        counts, stats = oracle.scan_stream_cc(rows, g, cs, ct, nc, nt)
+        passes += 1
+        if passes >= 50:
+            break
+    dt = (time.perf_counter() - t0) / passes
+    gpu_counts, gpu_stats = table.scan_case_control(0, sample)
+    parity = bool(np.array_equal(gpu_counts, counts)) and bool(
+        np.allclose(gpu_stats, stats, rtol=1e-10, atol=1e-12))
+    threads = os.cpu_count() or 1
+    t1 = time.perf_counter()
+    mt_passes = 0
+    while mt_passes < 2 or time.perf_counter() - t1 < 2.0:
+        oracle.scan_stream_cc(rows, g, cs, ct, nc, nt, threads=threads)
+        mt_passes += 1
+    dt_mt = (time.perf_counter() - t1) / mt_passes
+    return {
+        "value": sample / dt, "unit": "SNPs/s", "cores": 1, "kind": "port",
+        "sample": f"first {sample} SNPs x {n_samples} samples of the same synthetic table, "
+                  f"{passes} passes, faithful single-thread LUT-popcount port",
+        "GBps": sample * bytes_per_snp / dt / 1e9,
+        "gpu_parity_on_sample": parity,
+        "best_effort_all_cores": {"value": sample / dt_mt, "unit": "SNPs/s", "cores": threads,
+                                  "GBps": sample * bytes_per_snp / dt_mt / 1e9,
+                                  "note": "hardware popcount, pthreads over SNP ranges"},
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import libgwaspp_amd as gw
+    from libgwaspp_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available() or gw.device_count() == 0:
+        raise SystemExit("bench.py: no GPU visible; the scan has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    n_samples, n_snps, wl_text = WORKLOADS[args.workload]
+    if args.snps:
+        n_snps = args.snps
+    table = gw.GwTable(n_samples, n_snps, device=local_rank)
+    if args.unroll:
+        table.set_option(capi.OPT_UNROLL, args.unroll)
+    if args.threads:
+        table.set_option(capi.OPT_BLOCK_THREADS, args.threads)
+    if args.blocks_per_cu:
+        table.set_option(capi.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    if args.mask_lds >= 0:
+        table.set_option(capi.OPT_MASK_IN_LDS, args.mask_lds)
+    if args.nt >= 0:
+        table.set_option(capi.OPT_NONTEMPORAL, args.nt)
+    t_setup = time.perf_counter()
+    table.simulate(SEED, rank * n_snps, 0)   # no missing calls, like data/simulate_data.cpp
+    table.simulate_phenotype(SEED)           # identical masks on every rank (same seed)
+    t_setup = time.perf_counter() - t_setup
+
+    # result buffers (torch = device memory + streams + RCCL plumbing)
+    n_chunks = max(1, min(args.chunks if world > 1 else 1, n_snps))
+    bounds = [(n_snps * c) // n_chunks for c in range(n_chunks + 1)]
+    bufs, gathers = [], []
+    for c in range(n_chunks):
+        rows = bounds[c + 1] - bounds[c]
+        bufs.append(torch.empty(rows * RECORD_BYTES, dtype=torch.uint8, device="cuda"))
+        if world > 1 and rank == 0:
+            gathers.append([torch.empty(rows * RECORD_BYTES, dtype=torch.uint8, device="cuda")
+                            for _ in range(world)])
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    def step():
+        works = []
+        for c in range(n_chunks):
+            rows = bounds[c + 1] - bounds[c]
+            base = bufs[c].data_ptr()
+            table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
+            if world > 1:
+                works.append(dist.gather(bufs[c], gathers[c] if rank == 0 else None, dst=0, async_op=True))
+        for w in works:
+            w.wait()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    table.timer_start(sptr)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms_total = table.timer_stop(sptr)  # HIP events on the launching stream; syncs on the stop event
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        geo = table.geometry
+        total_snps = n_snps * world
+        launches = args.steps * n_chunks
+        kernel_ms = kernel_ms_total / max(1, launches)
+        alg_bytes_per_launch = (n_snps / n_chunks) * (n_samples / 4.0)
+        achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        # empirical streaming-read ceiling on the same buffer
+        probe_ms = []
+        for _ in range(3):
+            table.timer_start(None)
+            nbytes = table.stream_read_probe(None)
+            probe_ms.append(table.timer_stop(None))
+        probe_gbps = nbytes / (min(probe_ms) * 1e-3) / 1e9 if nbytes else None
+        shape = {"unroll": table.get_option(capi.OPT_UNROLL),
+                 "mask_in_lds": table.get_option(capi.OPT_MASK_IN_LDS),
+                 "block_threads": table.get_option(capi.OPT_BLOCK_THREADS),
+                 "blocks_per_cu": table.get_option(capi.OPT_BLOCKS_PER_CU),
+                 "nontemporal": table.get_option(capi.OPT_NONTEMPORAL)}
+        out = {
+            "metric": "SNPs/sec case/control chi2 scan",
+            "value": total_snps / (elapsed / args.steps),
+            "unit": "SNPs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl_text, "n_samples": n_samples, "n_snps_per_gpu": n_snps,
+                "n_snps_total": total_snps, "table_GB_per_gpu": geo.device_table_bytes / 1e9,
+                "algorithmic_bytes_per_snp": n_samples / 4.0,
+                "input": f"restated data/simulate_data.cpp (affy6 MAF spectrum, HWE, coin-flip phenotype), "
+                         f"counter-based RNG seed {SEED:#x}, generated in HBM in {t_setup:.2f} s",
+                "sharding": "contiguous SNP ranges, one rank per GPU" if world > 1 else "single GPU",
+                "exchange": f"RCCL gather of {RECORD_BYTES} B/SNP to rank 0 in {n_chunks} chunks, "
+                            "overlapped with the scan" if world > 1 else "none",
+                "kernel_shape": shape, "stats_dtype": "f64",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+                "kernel": "gw::k_scan_cc", "kernel_ms": kernel_ms, "launches_timed": launches,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                "stream_read_probe_GBps": probe_gbps,
+                "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(table, n_samples, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    table.close()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

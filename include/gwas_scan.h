@@ -1,0 +1,237 @@
+/*
+ * gwas_scan.h -- C-ABI of the MI355X-native per-SNP association scan.
+ *
+ * This is the drop-in boundary for ONE path of putnampp/libgwaspp: the
+ * per-SNP scan over the 2-bit-packed genotype table (genotype counts ->
+ * case/control contingency -> MAF / HWE / chi-square).  Each entry point
+ * names the reference interface it replaces; paths are relative to
+ * /root/reference/src/libgwaspp/.  The reference is single-process C++ with
+ * no FFI of its own, so "what its FFI for this path would bind" is the set of
+ * virtuals of genetics::GenoTable that the scan harnesses in
+ * algorithms/maf_func.cpp call, batched over SNP ranges.
+ * INTEGRATION.md shows the GenoTable subclass a maintainer would add on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; handles are opaque.
+ *   - every call returns 0 (GW_OK) or a negative gw_status; gw_last_error()
+ *     gives the message of the calling thread's last failure.  The reference
+ *     aborts via assert() on the same conditions (CMakeLists.txt:34 keeps
+ *     asserts on at -O3); the C++ mirror in libgwaspp_amd/host turns a
+ *     non-zero status back into an abort.
+ *   - a handle is thread-compatible, not thread-safe (the reference's tables
+ *     are not re-entrant either: SURVEY.md section 5).
+ *   - "stream packing" / "block packing" are the reference's two 2-bit row
+ *     layouts: CompressedGenotypeTable5 (two bit-planes per row,
+ *     genotype/compressed_genotype_table5.cpp:44-72) and
+ *     CompressedGenotypeTable3 (2 bits per genotype, table3.cpp:44-67), both
+ *     with one uint16 header block in front of each row.
+ *   - there is NO CPU fallback: without a HIP device every compute entry
+ *     point fails with GW_E_HIP.
+ */
+#ifndef GWAS_SCAN_H
+#define GWAS_SCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gw_status {
+    GW_OK = 0,
+    GW_E_INVALID = -1, /* bad argument                                     */
+    GW_E_HIP = -2,     /* HIP runtime / no device / kernel launch failure   */
+    GW_E_NOMEM = -3,   /* host or device allocation failed                  */
+    GW_E_STATE = -4,   /* call order (e.g. scan before masks were set)      */
+    GW_E_RANGE = -5,   /* SNP / sample index outside the table              */
+    GW_E_FORMAT = -6   /* genotype text the reference would assert on       */
+} gw_status;
+
+/* row layouts of the reference, incl. the uint16 header block */
+typedef enum gw_layout {
+    GW_LAYOUT_STREAM = 5, /* CompressedGenotypeTable5 (e2BitStream)           */
+    GW_LAYOUT_BLOCK = 3   /* CompressedGenotypeTable3 (e2BitBlockCompression) */
+} gw_layout;
+
+typedef struct gw_table gw_table; /* opaque */
+
+/* per-SNP result records */
+#define GW_N_COUNTS 8 /* case {aa,ab,bb,xx}, control {aa,ab,bb,xx}: two
+                         frequency_table (genotype/common_genotype.h:67-75) */
+#define GW_N_STATS 8  /* doubles, see gw_scan_case_control                  */
+#define GW_N_CONTIN 16 /* CONTIN_TABLE_T (common_genotype.h:182-192)         */
+
+typedef struct gw_geometry {
+    uint32_t n_samples;
+    uint64_t n_snps;
+    uint32_t stream_blocks;     /* uint16 blocks per plane, reference stream packing */
+    uint32_t block_blocks;      /* uint16 data blocks per row, reference block packing */
+    uint32_t stream_row_bytes;  /* reference row stride, stream packing (header incl.) */
+    uint32_t block_row_bytes;   /* reference row stride, block packing (header incl.)  */
+    uint32_t device_units;      /* 16-byte units per plane in HBM                       */
+    uint32_t device_plane_bytes;/* plane stride in HBM (128-byte multiple)              */
+    uint64_t device_row_bytes;  /* row stride in HBM = 2 planes                         */
+    uint64_t device_table_bytes;
+    uint64_t algorithmic_bytes_per_snp; /* n_samples/4, SURVEY.md 8d              */
+} gw_geometry;
+
+typedef struct gw_device_info {
+    char name[128];
+    char arch[32];
+    int compute_units;
+    int lds_bytes_per_cu;
+    uint64_t hbm_bytes;
+    uint64_t hbm_free_bytes;
+} gw_device_info;
+
+/* ---- library / device ------------------------------------------------- */
+const char *gw_last_error(void);
+const char *gw_version(void);
+int gw_device_count(int *count);
+int gw_device_info_get(int device, gw_device_info *out);
+
+/* ---- table lifetime ------------------------------------------------------
+ * replaces: new CompressedGenotypeTable5(markers, individs) chosen by
+ * GeneticData::updateGenotypeTable (genetics/genetic_data.cpp:46-80) and the
+ * table destructors.  n_snps = rows->included_size(), n_samples =
+ * columns->included_size() (util/table/table.h:49-74).  Allocates the whole
+ * table in HBM, zero-filled ("unknown" everywhere, as table5.cpp:82-83). */
+int gw_table_create(int device, uint32_t n_samples, uint64_t n_snps, gw_table **out);
+int gw_table_destroy(gw_table *t);
+int gw_table_geometry(const gw_table *t, gw_geometry *out);
+
+/* ---- ingest --------------------------------------------------------------
+ * gw_table_add_genotype_row replaces GenoTable::addGenotypeRow(int r, const
+ * char *b, const char *e, char delim) (genotype/geno_table.h:53;
+ * table5.cpp:277-365): text "AC<d>AA<d>..." -> 2-bit codes with first-seen
+ * labelling and the row header (HeaderStateMachine,
+ * common_genotype.h:257-304).  Rows are packed on the host and staged; they
+ * reach HBM at gw_table_flush() or at the next scan.  GW_E_FORMAT where the
+ * reference asserts (second heterozygote spelling, fourth genotype). */
+int gw_table_add_genotype_row(gw_table *t, uint64_t snp, const char *begin, const char *end,
+                              char delim);
+int gw_table_flush(gw_table *t);
+
+/* Bulk hand-over of rows ALREADY in a reference packing (the bytes at
+ * Table<DataBlock>::data, header block included, `row_stride_bytes` apart):
+ * re-strided on the device into the HBM layout. */
+int gw_table_upload_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const void *rows,
+                         size_t row_stride_bytes, int layout);
+/* The reverse (used by operator()(r,c) in the C++ mirror, by tests and by the
+ * CPU-baseline sample): rows come back in a reference packing, header incl. */
+int gw_table_download_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, void *rows,
+                           size_t row_stride_bytes, int layout);
+/* row header blocks (uint16 per SNP), as table5.cpp:363 stores them */
+int gw_table_get_headers(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint16_t *headers);
+
+/* Synthetic input generated in HBM: restates data/simulate_data.cpp:150-235
+ * (MAF-spectrum driven genotypes in HWE, coin-flip phenotype) with a
+ * counter-based RNG so that any row can be regenerated anywhere.  Row r of
+ * the table gets global SNP index snp_global_begin + r.  missing_q16 =
+ * missing-call probability * 65536 (0 = none, like the reference simulator).
+ * gw_table_simulate_phenotype also installs the case/control masks. */
+int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16);
+int gw_table_simulate_phenotype(gw_table *t, uint64_t seed);
+
+/* ---- phenotype masks -----------------------------------------------------
+ * replaces handing a CaseControlSet to the table: the arguments are
+ * CaseControlSet::stream_case_begin() / stream_control_begin()
+ * (analyzable/case_control_set.h:64-74; one bit per sample, n_blocks =
+ * stream_block_count uint16) and getCaseCount()/getControlCount(). */
+int gw_table_set_case_control(gw_table *t, const uint16_t *case_stream, const uint16_t *ctrl_stream,
+                              uint32_t n_blocks, uint32_t case_count, uint32_t ctrl_count);
+int gw_table_get_case_control(gw_table *t, uint16_t *case_stream, uint16_t *ctrl_stream,
+                              uint32_t n_blocks, uint32_t *case_count, uint32_t *ctrl_count);
+
+/* ---- the scan ------------------------------------------------------------
+ * gw_scan_case_control replaces the loop of inline_cc_maf
+ * (algorithms/maf_func.cpp:292-316):
+ *     for i in [snp_begin, snp_begin+n):
+ *         gt.getCaseControlGenotypeDistribution(i, ccs, ccgd)   table5.cpp:609-657
+ *         MinorAlleleFrequency(cases) / (controls)              maf_func.h:46-54
+ * counts[n][8]: case {aa,ab,bb,xx}, control {aa,ab,bb,xx}; xx = group count
+ *   - aa - ab - bb (table5.cpp:649,653).  Bit-exact integers.
+ * stats[n][8] (may be NULL: counts only):
+ *   [0] MinorAlleleFrequency(cases)    reference formula (quirk Q5)
+ *   [1] MinorAlleleFrequency(controls)
+ *   [2] conventional MAF over cases+controls, min(p,1-p), p=(2aa+ab)/(2n)
+ *   [3] HWE chi-square (df 1) on controls
+ *   [4] HWE chi-square (df 1) on cases+controls
+ *   [5] genotypic 2x3 Pearson chi-square (df 2)
+ *   [6] allelic 2x2 Pearson chi-square (df 1)
+ *   [7] call rate
+ *   [3..7] are NOT in the reference (it has no single-SNP test); they are
+ *   defined in DESIGN.md and computed in FP64 in the same kernel.
+ * Host-pointer form: results are copied back before returning. */
+int gw_scan_case_control(gw_table *t, uint64_t snp_begin, uint64_t n_snps, uint32_t *counts,
+                         double *stats);
+
+/* Device-pointer form for callers that keep results in HBM (bench, the
+ * multi-GPU gather): d_counts / d_stats are device pointers with room for
+ * n_snps records (d_stats may be NULL), the launch goes to `hip_stream`
+ * (a hipStream_t; NULL = the handle's own stream) and is NOT synchronised. */
+int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_counts,
+                                void *d_stats, void *hip_stream);
+
+/* gw_scan_distribution replaces the loop of genotype_dist_performance /
+ * inline_maf_print (maf_func.cpp:271-290,318-335) over
+ * getGenotypeDistribution(i, dist) (table5.cpp:577-607):
+ * dist[n][4] = {aa, ab, bb, xx}, xx = n_samples - aa - ab - bb (the exact
+ * missing count; the reference's stream table adds its pad bits here, quirk
+ * Q3 -- the C++ mirror re-adds them). */
+int gw_scan_distribution(gw_table *t, uint64_t snp_begin, uint64_t n_snps, uint32_t *dist);
+int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_dist,
+                                void *hip_stream);
+
+/* ---- pairwise contingency (callers of the scan) -----
+ * replaces getContingencyTable(i, j, ct) (table5.cpp:749-800) and
+ * getCaseControlContingencyTable(i, j, ccs, ccct) (table5.cpp:806-895) for a
+ * list of SNP pairs.  pairs[n][2]; out[n][16] row-major 4x4
+ * {aa,ab,bb,xx} x {aa,ab,bb,xx}; for the case/control form out_case and
+ * out_ctrl are both required. */
+int gw_pair_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, uint32_t *out);
+int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs,
+                                     uint32_t *out_case, uint32_t *out_ctrl);
+
+/* ---- measurement ----------------------------------------------------------
+ * HIP events on the stream the kernels are launched on (NULL = the handle's
+ * stream).  gw_timer_stop synchronises on the stop event and returns the
+ * elapsed milliseconds since the matching gw_timer_start. */
+int gw_timer_start(gw_table *t, void *hip_stream);
+int gw_timer_stop(gw_table *t, void *hip_stream, float *elapsed_ms);
+/* Plain 16-byte-per-lane read-reduce over the table's HBM allocation: the
+ * empirical streaming-read ceiling SURVEY.md 8d asks to report next to the
+ * nominal 8 TB/s.  Returns the bytes one launch reads. */
+int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read);
+int gw_synchronize(gw_table *t);
+
+/* kernel-shape knobs for A/B measurement (defaults are chosen at create) */
+typedef enum gw_option {
+    GW_OPT_UNROLL = 1,       /* 16-byte units per lane in flight per plane: 1,2,4,8 */
+    GW_OPT_MASK_IN_LDS = 2,  /* 1: stage masks in LDS (default when they fit); 0: read via L2 */
+    GW_OPT_BLOCKS_PER_CU = 3,/* persistent workgroups per CU (0 = auto)          */
+    GW_OPT_NONTEMPORAL = 4,  /* 1: nt loads for the genotype stream (default)     */
+    GW_OPT_BLOCK_THREADS = 5 /* threads per workgroup: 256, 512, 1024 (0 = auto) */
+} gw_option;
+int gw_set_option(gw_table *t, int option, int64_t value);
+int gw_get_option(gw_table *t, int option, int64_t *value);
+
+/* ---- host-only helpers (no device needed) ---------------------------------
+ * The packer behind gw_table_add_genotype_row, exposed so that the host logic
+ * can be checked without a GPU: packs one text row into a reference packing
+ * (row must hold the layout's blocks-per-row uint16, header first). */
+int gw_pack_genotype_row(const char *begin, const char *end, char delim, uint32_t n_samples,
+                         int layout, uint16_t *row);
+/* CaseControlSet::setCases / setControls (case_control_set.cpp:77-150) in the
+ * stream packing: idx[n_idx] column indices -> mask of gw_stream_blocks(n)
+ * uint16; *count = members (duplicates once). */
+int gw_build_stream_mask(const int32_t *idx, size_t n_idx, uint32_t n_samples, uint16_t *mask,
+                         uint32_t *count);
+uint32_t gw_stream_blocks(uint32_t n_samples); /* N/16+1 -> x4 (table5.cpp:52-60) */
+uint32_t gw_block_blocks(uint32_t n_samples);  /* N/8+1  -> x4 (table3.cpp:52-60) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWAS_SCAN_H */

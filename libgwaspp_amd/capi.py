@@ -1,0 +1,307 @@
+"""ctypes view of the C-ABI in include/gwas_scan.h (libgwaspp_amd/libgwscan.so).
+
+Plumbing only: argument marshalling with numpy, no arithmetic.  There is no
+fallback path -- if the shared library is missing or no GPU is present the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libgwscan.so")
+
+LAYOUT_STREAM = 5
+LAYOUT_BLOCK = 3
+N_COUNTS = 8
+N_STATS = 8
+
+OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS = 1, 2, 3, 4, 5
+
+
+class GwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gw status {code}: {msg}")
+        self.code = code
+
+
+class Geometry(C.Structure):
+    _fields_ = [("n_samples", C.c_uint32), ("n_snps", C.c_uint64), ("stream_blocks", C.c_uint32),
+                ("block_blocks", C.c_uint32), ("stream_row_bytes", C.c_uint32),
+                ("block_row_bytes", C.c_uint32), ("device_units", C.c_uint32),
+                ("device_plane_bytes", C.c_uint32), ("device_row_bytes", C.c_uint64),
+                ("device_table_bytes", C.c_uint64), ("algorithmic_bytes_per_snp", C.c_uint64)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int),
+                ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_uint64), ("hbm_free_bytes", C.c_uint64)]
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of libgwscan.so (in-tree)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(_LIB):
+        os.remove(_LIB)
+    subprocess.run(["make", "-C", src_dir, "-s"], check=True)
+    return _LIB
+
+
+_lib = None
+
+# every extern "C" symbol include/gwas_scan.h declares
+EXPORTS = [
+    "gw_last_error", "gw_version", "gw_device_count", "gw_device_info_get", "gw_table_create",
+    "gw_table_destroy", "gw_table_geometry", "gw_table_add_genotype_row", "gw_table_flush",
+    "gw_table_upload_rows", "gw_table_download_rows", "gw_table_get_headers", "gw_table_simulate",
+    "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
+    "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
+    "gw_scan_distribution_device", "gw_pair_contingency", "gw_pair_case_control_contingency",
+    "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_set_option",
+    "gw_get_option", "gw_pack_genotype_row", "gw_build_stream_mask", "gw_stream_blocks",
+    "gw_block_blocks",
+]
+
+
+def library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise GwError(-2, f"{_LIB} is not built (run __graft_entry__.build() / make -C libgwaspp_amd/csrc); "
+                          "there is no CPU fallback")
+    L = C.CDLL(_LIB)
+    vp, u16p, u32p, f64p = C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    L.gw_last_error.restype = C.c_char_p
+    L.gw_version.restype = C.c_char_p
+    L.gw_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.gw_device_info_get.argtypes = [C.c_int, C.POINTER(DeviceInfo)]
+    L.gw_table_create.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.POINTER(vp)]
+    L.gw_table_destroy.argtypes = [vp]
+    L.gw_table_geometry.argtypes = [vp, C.POINTER(Geometry)]
+    L.gw_table_add_genotype_row.argtypes = [vp, C.c_uint64, vp, vp, C.c_char]
+    L.gw_table_flush.argtypes = [vp]
+    L.gw_table_upload_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
+    L.gw_table_download_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
+    L.gw_table_get_headers.argtypes = [vp, C.c_uint64, C.c_uint64, u16p]
+    L.gw_table_simulate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.gw_table_simulate_phenotype.argtypes = [vp, C.c_uint64]
+    L.gw_table_set_case_control.argtypes = [vp, u16p, u16p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.gw_table_get_case_control.argtypes = [vp, u16p, u16p, C.c_uint32, u32p, u32p]
+    L.gw_scan_case_control.argtypes = [vp, C.c_uint64, C.c_uint64, u32p, f64p]
+    L.gw_scan_case_control_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.gw_scan_distribution.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
+    L.gw_scan_distribution_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp]
+    L.gw_pair_contingency.argtypes = [vp, u32p, C.c_uint64, u32p]
+    L.gw_pair_case_control_contingency.argtypes = [vp, u32p, C.c_uint64, u32p, u32p]
+    L.gw_timer_start.argtypes = [vp, vp]
+    L.gw_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.gw_stream_read_probe.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    L.gw_synchronize.argtypes = [vp]
+    L.gw_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.gw_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.gw_pack_genotype_row.argtypes = [vp, vp, C.c_char, C.c_uint32, C.c_int, u16p]
+    L.gw_build_stream_mask.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, u16p, u32p]
+    L.gw_stream_blocks.argtypes = [C.c_uint32]
+    L.gw_stream_blocks.restype = C.c_uint32
+    L.gw_block_blocks.argtypes = [C.c_uint32]
+    L.gw_block_blocks.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise GwError(rc, library().gw_last_error().decode())
+
+
+def _p16(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint16))
+
+
+def _p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = library().gw_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def device_info(device: int = 0) -> DeviceInfo:
+    d = DeviceInfo()
+    _check(library().gw_device_info_get(device, C.byref(d)))
+    return d
+
+
+def stream_blocks(n: int) -> int:
+    return library().gw_stream_blocks(n)
+
+
+def block_blocks(n: int) -> int:
+    return library().gw_block_blocks(n)
+
+
+def pack_genotype_row(text: bytes, n_samples: int, layout: int = LAYOUT_STREAM) -> np.ndarray:
+    """Host packer behind gw_table_add_genotype_row (no GPU needed)."""
+    nb = 2 * stream_blocks(n_samples) + 1 if layout == LAYOUT_STREAM else block_blocks(n_samples) + 1
+    row = np.zeros(nb, dtype=np.uint16)
+    buf = C.create_string_buffer(text, len(text))
+    base = C.addressof(buf)
+    _check(library().gw_pack_genotype_row(base, base + len(text), b"\t", n_samples, layout, _p16(row)))
+    return row
+
+
+def build_stream_mask(idx, n_samples: int):
+    idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int32))
+    mask = np.zeros(stream_blocks(n_samples), dtype=np.uint16)
+    cnt = C.c_uint32(0)
+    _check(library().gw_build_stream_mask(idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, n_samples,
+                                          _p16(mask), C.byref(cnt)))
+    return mask, cnt.value
+
+
+class GwTable:
+    """One genotype table resident in HBM (opaque gw_table handle)."""
+
+    def __init__(self, n_samples: int, n_snps: int, device: int = 0):
+        self._L = library()
+        self._h = C.c_void_p()
+        _check(self._L.gw_table_create(device, n_samples, n_snps, C.byref(self._h)))
+        self.geometry = Geometry()
+        _check(self._L.gw_table_geometry(self._h, C.byref(self.geometry)))
+        self.n_samples, self.n_snps = n_samples, n_snps
+
+    def close(self):
+        if self._h:
+            self._L.gw_table_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- ingest
+    def add_genotype_row(self, snp: int, text: bytes, delim: bytes = b"\t"):
+        buf = C.create_string_buffer(text, len(text))
+        base = C.addressof(buf)
+        _check(self._L.gw_table_add_genotype_row(self._h, snp, base, base + len(text), delim))
+
+    def flush(self):
+        _check(self._L.gw_table_flush(self._h))
+
+    def upload_rows(self, snp_begin: int, rows: np.ndarray, layout: int = LAYOUT_STREAM):
+        rows = np.ascontiguousarray(rows, dtype=np.uint16)
+        assert rows.ndim == 2
+        _check(self._L.gw_table_upload_rows(self._h, snp_begin, rows.shape[0], rows.ctypes.data,
+                                            rows.shape[1] * 2, layout))
+
+    def download_rows(self, snp_begin: int, n_rows: int, layout: int = LAYOUT_STREAM) -> np.ndarray:
+        g = self.geometry
+        nb = (g.stream_row_bytes if layout == LAYOUT_STREAM else g.block_row_bytes) // 2
+        rows = np.zeros((n_rows, nb), dtype=np.uint16)
+        _check(self._L.gw_table_download_rows(self._h, snp_begin, n_rows, rows.ctypes.data, nb * 2, layout))
+        return rows
+
+    def headers(self, snp_begin: int, n_rows: int) -> np.ndarray:
+        h = np.zeros(n_rows, dtype=np.uint16)
+        _check(self._L.gw_table_get_headers(self._h, snp_begin, n_rows, _p16(h)))
+        return h
+
+    def simulate(self, seed: int, snp_global_begin: int = 0, missing_q16: int = 0):
+        _check(self._L.gw_table_simulate(self._h, seed, snp_global_begin, missing_q16))
+
+    def simulate_phenotype(self, seed: int):
+        _check(self._L.gw_table_simulate_phenotype(self._h, seed))
+
+    # ---- masks
+    def set_case_control(self, case_stream, ctrl_stream, case_count: int, ctrl_count: int):
+        cs = np.ascontiguousarray(case_stream, dtype=np.uint16)
+        ct = np.ascontiguousarray(ctrl_stream, dtype=np.uint16)
+        _check(self._L.gw_table_set_case_control(self._h, _p16(cs), _p16(ct), cs.size, case_count, ctrl_count))
+
+    def get_case_control(self):
+        nb = self.geometry.stream_blocks
+        cs, ct = np.zeros(nb, np.uint16), np.zeros(nb, np.uint16)
+        nc, nt = C.c_uint32(), C.c_uint32()
+        _check(self._L.gw_table_get_case_control(self._h, _p16(cs), _p16(ct), nb, C.byref(nc), C.byref(nt)))
+        return cs, ct, nc.value, nt.value
+
+    # ---- scans (host results)
+    def scan_case_control(self, snp_begin: int = 0, n_snps: int | None = None, stats: bool = True):
+        n = self.n_snps - snp_begin if n_snps is None else n_snps
+        counts = np.zeros((n, N_COUNTS), dtype=np.uint32)
+        st = np.zeros((n, N_STATS), dtype=np.float64) if stats else None
+        _check(self._L.gw_scan_case_control(self._h, snp_begin, n, _p32(counts),
+                                            st.ctypes.data_as(C.POINTER(C.c_double)) if stats else None))
+        return counts, st
+
+    def scan_distribution(self, snp_begin: int = 0, n_snps: int | None = None):
+        n = self.n_snps - snp_begin if n_snps is None else n_snps
+        dist = np.zeros((n, 4), dtype=np.uint32)
+        _check(self._L.gw_scan_distribution(self._h, snp_begin, n, _p32(dist)))
+        return dist
+
+    # ---- scans (device results; pointers are raw device addresses)
+    def scan_case_control_device(self, snp_begin: int, n_snps: int, d_counts: int, d_stats: int | None,
+                                 stream: int | None = None):
+        _check(self._L.gw_scan_case_control_device(self._h, snp_begin, n_snps, d_counts, d_stats, stream))
+
+    def scan_distribution_device(self, snp_begin: int, n_snps: int, d_dist: int, stream: int | None = None):
+        _check(self._L.gw_scan_distribution_device(self._h, snp_begin, n_snps, d_dist, stream))
+
+    # ---- pairs
+    def pair_contingency(self, pairs) -> np.ndarray:
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros((pairs.shape[0], 16), dtype=np.uint32)
+        _check(self._L.gw_pair_contingency(self._h, _p32(pairs), pairs.shape[0], _p32(out)))
+        return out
+
+    def pair_case_control_contingency(self, pairs):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        a = np.zeros((pairs.shape[0], 16), dtype=np.uint32)
+        b = np.zeros((pairs.shape[0], 16), dtype=np.uint32)
+        _check(self._L.gw_pair_case_control_contingency(self._h, _p32(pairs), pairs.shape[0], _p32(a), _p32(b)))
+        return a, b
+
+    # ---- measurement
+    def timer_start(self, stream: int | None = None):
+        _check(self._L.gw_timer_start(self._h, stream))
+
+    def timer_stop(self, stream: int | None = None) -> float:
+        ms = C.c_float(0)
+        _check(self._L.gw_timer_stop(self._h, stream, C.byref(ms)))
+        return ms.value
+
+    def stream_read_probe(self, stream: int | None = None) -> int:
+        b = C.c_uint64(0)
+        _check(self._L.gw_stream_read_probe(self._h, stream, C.byref(b)))
+        return b.value
+
+    def synchronize(self):
+        _check(self._L.gw_synchronize(self._h))
+
+    def set_option(self, option: int, value: int):
+        _check(self._L.gw_set_option(self._h, option, value))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int64(0)
+        _check(self._L.gw_get_option(self._h, option, C.byref(v)))
+        return v.value

@@ -1,0 +1,646 @@
+// gw_capi.cpp -- the C-ABI of include/gwas_scan.h on top of the gfx950
+// kernels.  Compiled with hipcc into libgwaspp_amd/libgwscan.so.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gwas_scan.h"
+#include "gw_kernels.h"
+#include "gw_pack.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define GW_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return fail(e__ == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e__));                                           \
+    } while (0)
+
+constexpr size_t kStagingBytes = 64u << 20;
+
+}  // namespace
+
+struct gw_table {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    gw::TableView tv{};
+    gw_geometry geo{};
+    int compute_units = 0;
+    size_t lds_cap = 0;
+
+    gw::u32x4 *d_case = nullptr, *d_ctrl = nullptr;
+    uint32_t case_count = 0, ctrl_count = 0;
+    bool masks_set = false;
+    std::vector<uint16_t> h_case, h_ctrl;  // reference stream packing, as handed in
+
+    std::vector<uint16_t> headers;  // row header blocks (table5.cpp:363)
+
+    uint8_t *d_staging = nullptr;  // reference-packed rows in flight to/from HBM
+    size_t staging_bytes = 0;
+    uint32_t *d_scratch32 = nullptr;  // results of the host-pointer scan forms
+    size_t scratch32_bytes = 0;
+    double *d_scratch64 = nullptr;
+    size_t scratch64_bytes = 0;
+    uint32_t *d_misc = nullptr;  // 16 x uint32 (probe sink, phenotype counts)
+
+    // rows packed by gw_table_add_genotype_row, waiting for the next flush
+    std::vector<uint16_t> pending;
+    uint64_t pending_begin = 0;
+    uint32_t pending_rows = 0, pending_cap = 0;
+
+    // kernel shape
+    int opt_unroll = 4, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0;
+};
+
+namespace {
+
+int use_device(gw_table *t) {
+    GW_HIP(hipSetDevice(t->device));
+    return GW_OK;
+}
+
+hipStream_t pick_stream(gw_table *t, void *s) { return s ? (hipStream_t)s : t->stream; }
+
+gw::ScanShape scan_shape(const gw_table *t) {
+    gw::ScanShape sh{};
+    const size_t need = (size_t)2 * t->tv.units * sizeof(gw::u32x4);
+    const bool fits = need <= t->lds_cap;
+    sh.mask_in_lds = (t->opt_mask_lds < 0) ? (fits ? 1 : 0) : (t->opt_mask_lds && fits ? 1 : 0);
+    sh.lds_bytes = sh.mask_in_lds ? need : 0;
+    sh.unroll = t->opt_unroll;
+    sh.nontemporal = t->opt_nt;
+    int threads = t->opt_threads;
+    int per_cu = t->opt_blocks_per_cu;
+    const int lds_limit = sh.mask_in_lds ? (int)(t->lds_cap / need) : 8;
+    if (threads == 0) threads = (sh.mask_in_lds && lds_limit < 2) ? 1024 : 512;
+    if (per_cu == 0) per_cu = std::max(1, std::min(lds_limit, 2048 / threads));
+    per_cu = std::max(1, std::min(per_cu, lds_limit));
+    sh.block_threads = threads;
+    sh.grid_blocks = t->compute_units * per_cu;
+    return sh;
+}
+
+int ensure_scratch(gw_table *t, size_t bytes32, size_t bytes64) {
+    if (bytes32 > t->scratch32_bytes) {
+        if (t->d_scratch32) GW_HIP(hipFree(t->d_scratch32));
+        t->d_scratch32 = nullptr;
+        t->scratch32_bytes = 0;
+        GW_HIP(hipMalloc((void **)&t->d_scratch32, bytes32));
+        t->scratch32_bytes = bytes32;
+    }
+    if (bytes64 > t->scratch64_bytes) {
+        if (t->d_scratch64) GW_HIP(hipFree(t->d_scratch64));
+        t->d_scratch64 = nullptr;
+        t->scratch64_bytes = 0;
+        GW_HIP(hipMalloc((void **)&t->d_scratch64, bytes64));
+        t->scratch64_bytes = bytes64;
+    }
+    return GW_OK;
+}
+
+int check_range(const gw_table *t, uint64_t begin, uint64_t n) {
+    if (begin > t->tv.n_snps || n > t->tv.n_snps - begin)
+        return fail(GW_E_RANGE, "SNP range [%llu, +%llu) outside the table (%llu SNPs)",
+                    (unsigned long long)begin, (unsigned long long)n,
+                    (unsigned long long)t->tv.n_snps);
+    if (n > 0xFFFFFFFFull) return fail(GW_E_RANGE, "at most 2^32-1 SNPs per call");
+    return GW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gw_last_error(void) { return g_err.c_str(); }
+const char *gw_version(void) { return "libgwscan 0.1 (gfx950)"; }
+
+int gw_device_count(int *count) {
+    if (!count) return fail(GW_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(GW_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return GW_OK;
+}
+
+int gw_device_info_get(int device, gw_device_info *out) {
+    if (!out) return fail(GW_E_INVALID, "out is NULL");
+    hipDeviceProp_t p;
+    GW_HIP(hipGetDeviceProperties(&p, device));
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", p.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    out->hbm_bytes = p.totalGlobalMem;
+    GW_HIP(hipSetDevice(device));
+    size_t fr = 0, tot = 0;
+    GW_HIP(hipMemGetInfo(&fr, &tot));
+    out->hbm_free_bytes = fr;
+    return GW_OK;
+}
+
+uint32_t gw_stream_blocks(uint32_t n_samples) { return gw::stream_blocks(n_samples); }
+uint32_t gw_block_blocks(uint32_t n_samples) { return gw::block_blocks(n_samples); }
+
+int gw_table_create(int device, uint32_t n_samples, uint64_t n_snps, gw_table **out) {
+    if (!out) return fail(GW_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_samples == 0) return fail(GW_E_INVALID, "n_samples must be > 0");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(GW_E_HIP, "no HIP device: this library has no CPU fallback (%s)",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(GW_E_INVALID, "device %d of %d", device, ndev);
+    GW_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GW_HIP(hipGetDeviceProperties(&prop, device));
+
+    gw_table *t = new (std::nothrow) gw_table();
+    if (!t) return fail(GW_E_NOMEM, "out of host memory");
+    t->device = device;
+    t->compute_units = prop.multiProcessorCount;
+    // LDS a single workgroup may take: 160 KiB on gfx950 (64 KiB without opt-in)
+    t->lds_cap = std::max<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor);
+    if (t->lds_cap > (160u << 10)) t->lds_cap = 160u << 10;
+
+    gw_geometry &g = t->geo;
+    g.n_samples = n_samples;
+    g.n_snps = n_snps;
+    g.stream_blocks = gw::stream_blocks(n_samples);
+    g.block_blocks = gw::block_blocks(n_samples);
+    g.stream_row_bytes = gw::stream_row_blocks(n_samples) * 2u;
+    g.block_row_bytes = gw::block_row_blocks(n_samples) * 2u;
+    // 16-byte units per plane: enough for the reference's words (gbo/4 x 8 bytes)
+    const uint32_t words = g.stream_blocks / 4u;
+    g.device_units = (words + 1u) / 2u;
+    g.device_plane_bytes = ((g.device_units * 16u) + 127u) & ~127u;
+    g.device_row_bytes = 2ull * g.device_plane_bytes;
+    g.device_table_bytes = g.device_row_bytes * n_snps;
+    g.algorithmic_bytes_per_snp = n_samples / 4u;
+
+    t->tv.units = g.device_units;
+    t->tv.plane_stride_u = g.device_plane_bytes / 16u;
+    t->tv.row_stride_u = g.device_row_bytes / 16u;
+    t->tv.n_samples = n_samples;
+    t->tv.n_snps = n_snps;
+
+    auto bail = [&](int code) {
+        gw_table_destroy(t);
+        return code;
+    };
+#define GW_HIP_T(expr)                                                                       \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return bail(fail(e__ == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "%s: %s",   \
+                             #expr, hipGetErrorString(e__)));                                \
+    } while (0)
+    GW_HIP_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    GW_HIP_T(hipEventCreate(&t->ev_start));
+    GW_HIP_T(hipEventCreate(&t->ev_stop));
+    if (g.device_table_bytes) {
+        GW_HIP_T(hipMalloc((void **)&t->tv.base, g.device_table_bytes));
+        GW_HIP_T(hipMemsetAsync(t->tv.base, 0, g.device_table_bytes, t->stream));
+    }
+    const size_t mask_bytes = (size_t)t->tv.plane_stride_u * 16u;
+    GW_HIP_T(hipMalloc((void **)&t->d_case, mask_bytes));
+    GW_HIP_T(hipMalloc((void **)&t->d_ctrl, mask_bytes));
+    GW_HIP_T(hipMemsetAsync(t->d_case, 0, mask_bytes, t->stream));
+    GW_HIP_T(hipMemsetAsync(t->d_ctrl, 0, mask_bytes, t->stream));
+    GW_HIP_T(hipMalloc((void **)&t->d_misc, 16 * sizeof(uint32_t)));
+    GW_HIP_T(hipMemsetAsync(t->d_misc, 0, 16 * sizeof(uint32_t), t->stream));
+    const size_t max_ref_row = std::max(g.stream_row_bytes, g.block_row_bytes);
+    t->staging_bytes = std::max(kStagingBytes, max_ref_row);
+    GW_HIP_T(hipMalloc((void **)&t->d_staging, t->staging_bytes));
+    GW_HIP_T(gw::prepare_scan_kernels(t->lds_cap));
+    GW_HIP_T(hipStreamSynchronize(t->stream));
+#undef GW_HIP_T
+    try {
+        t->headers.assign(n_snps, 0);
+        t->pending_cap = (uint32_t)std::max<size_t>(1, std::min<size_t>(4096, (16u << 20) / g.stream_row_bytes));
+        t->pending.resize((size_t)t->pending_cap * (g.stream_row_bytes / 2u));
+    } catch (const std::bad_alloc &) {
+        return bail(fail(GW_E_NOMEM, "out of host memory"));
+    }
+    *out = t;
+    return GW_OK;
+}
+
+int gw_table_destroy(gw_table *t) {
+    if (!t) return GW_OK;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->tv.base) (void)hipFree(t->tv.base);
+    if (t->d_case) (void)hipFree(t->d_case);
+    if (t->d_ctrl) (void)hipFree(t->d_ctrl);
+    if (t->d_staging) (void)hipFree(t->d_staging);
+    if (t->d_scratch32) (void)hipFree(t->d_scratch32);
+    if (t->d_scratch64) (void)hipFree(t->d_scratch64);
+    if (t->d_misc) (void)hipFree(t->d_misc);
+    if (t->ev_start) (void)hipEventDestroy(t->ev_start);
+    if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return GW_OK;
+}
+
+int gw_table_geometry(const gw_table *t, gw_geometry *out) {
+    if (!t || !out) return fail(GW_E_INVALID, "NULL argument");
+    *out = t->geo;
+    return GW_OK;
+}
+
+// ---------------------------------------------------------------- ingest
+
+int gw_table_upload_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const void *rows,
+                         size_t row_stride_bytes, int layout) {
+    if (!t || (!rows && n_rows)) return fail(GW_E_INVALID, "NULL argument");
+    if (layout != GW_LAYOUT_STREAM && layout != GW_LAYOUT_BLOCK)
+        return fail(GW_E_INVALID, "layout must be GW_LAYOUT_STREAM or GW_LAYOUT_BLOCK");
+    int rc = check_range(t, snp_begin, n_rows);
+    if (rc) return rc;
+    const size_t ref_bytes = layout == GW_LAYOUT_STREAM ? t->geo.stream_row_bytes : t->geo.block_row_bytes;
+    const uint32_t ref_blocks = layout == GW_LAYOUT_STREAM ? t->geo.stream_blocks : t->geo.block_blocks;
+    if (row_stride_bytes < ref_bytes || (row_stride_bytes & 1u))
+        return fail(GW_E_INVALID, "row stride %zu: need an even value >= %zu", row_stride_bytes, ref_bytes);
+    if ((rc = use_device(t))) return rc;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, t->staging_bytes / ref_bytes);
+    const uint8_t *src = static_cast<const uint8_t *>(rows);
+    for (uint64_t done = 0; done < n_rows; done += chunk_rows) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, n_rows - done);
+        GW_HIP(hipMemcpy2DAsync(t->d_staging, ref_bytes, src + done * row_stride_bytes, row_stride_bytes,
+                                ref_bytes, n, hipMemcpyHostToDevice, t->stream));
+        GW_HIP(gw::launch_restride_in(t->tv, snp_begin + done, n, t->d_staging, ref_bytes, layout,
+                                      ref_blocks, t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));
+        for (uint32_t r = 0; r < n; ++r) {
+            uint16_t h;
+            std::memcpy(&h, src + (done + r) * row_stride_bytes, 2);
+            t->headers[snp_begin + done + r] = h;
+        }
+    }
+    return GW_OK;
+}
+
+int gw_table_download_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, void *rows,
+                           size_t row_stride_bytes, int layout) {
+    if (!t || (!rows && n_rows)) return fail(GW_E_INVALID, "NULL argument");
+    if (layout != GW_LAYOUT_STREAM && layout != GW_LAYOUT_BLOCK)
+        return fail(GW_E_INVALID, "layout must be GW_LAYOUT_STREAM or GW_LAYOUT_BLOCK");
+    int rc = check_range(t, snp_begin, n_rows);
+    if (rc) return rc;
+    if ((rc = gw_table_flush(t))) return rc;
+    const size_t ref_bytes = layout == GW_LAYOUT_STREAM ? t->geo.stream_row_bytes : t->geo.block_row_bytes;
+    const uint32_t ref_blocks = layout == GW_LAYOUT_STREAM ? t->geo.stream_blocks : t->geo.block_blocks;
+    if (row_stride_bytes < ref_bytes || (row_stride_bytes & 1u))
+        return fail(GW_E_INVALID, "row stride %zu: need an even value >= %zu", row_stride_bytes, ref_bytes);
+    if ((rc = use_device(t))) return rc;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, t->staging_bytes / ref_bytes);
+    uint8_t *dst = static_cast<uint8_t *>(rows);
+    for (uint64_t done = 0; done < n_rows; done += chunk_rows) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, n_rows - done);
+        GW_HIP(gw::launch_restride_out(t->tv, snp_begin + done, n, t->d_staging, ref_bytes, layout,
+                                       ref_blocks, t->stream));
+        GW_HIP(hipMemcpy2DAsync(dst + done * row_stride_bytes, row_stride_bytes, t->d_staging, ref_bytes,
+                                ref_bytes, n, hipMemcpyDeviceToHost, t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));
+        for (uint32_t r = 0; r < n; ++r)
+            std::memcpy(dst + (done + r) * row_stride_bytes, &t->headers[snp_begin + done + r], 2);
+    }
+    return GW_OK;
+}
+
+int gw_table_get_headers(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint16_t *headers) {
+    if (!t || (!headers && n_rows)) return fail(GW_E_INVALID, "NULL argument");
+    int rc = check_range(t, snp_begin, n_rows);
+    if (rc) return rc;
+    if ((rc = gw_table_flush(t))) return rc;
+    std::memcpy(headers, t->headers.data() + snp_begin, n_rows * sizeof(uint16_t));
+    return GW_OK;
+}
+
+int gw_table_flush(gw_table *t) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    if (t->pending_rows == 0) return GW_OK;
+    const uint32_t n = t->pending_rows;
+    t->pending_rows = 0;
+    return gw_table_upload_rows(t, t->pending_begin, n, t->pending.data(), t->geo.stream_row_bytes,
+                                GW_LAYOUT_STREAM);
+}
+
+int gw_table_add_genotype_row(gw_table *t, uint64_t snp, const char *begin, const char *end, char delim) {
+    (void)delim;  // the reference skips one character after each allele pair, whatever it is
+    if (!t || !begin || !end) return fail(GW_E_INVALID, "NULL argument");
+    if (snp >= t->tv.n_snps) return fail(GW_E_RANGE, "SNP %llu outside the table", (unsigned long long)snp);
+    if (t->pending_rows && (snp != t->pending_begin + t->pending_rows || t->pending_rows == t->pending_cap)) {
+        int rc = gw_table_flush(t);
+        if (rc) return rc;
+    }
+    if (t->pending_rows == 0) t->pending_begin = snp;
+    uint16_t *row = t->pending.data() + (size_t)t->pending_rows * (t->geo.stream_row_bytes / 2u);
+    if (gw::pack_genotype_row(begin, end, t->geo.n_samples, false, row) != 0)
+        return fail(GW_E_FORMAT, "SNP %llu: genotype row the reference asserts on (second heterozygote "
+                                 "spelling, more than three genotypes, or too many samples)",
+                    (unsigned long long)snp);
+    ++t->pending_rows;
+    return GW_OK;
+}
+
+int gw_pack_genotype_row(const char *begin, const char *end, char delim, uint32_t n_samples, int layout,
+                         uint16_t *row) {
+    (void)delim;
+    if (!begin || !end || !row || n_samples == 0) return fail(GW_E_INVALID, "NULL argument");
+    if (layout != GW_LAYOUT_STREAM && layout != GW_LAYOUT_BLOCK)
+        return fail(GW_E_INVALID, "layout must be GW_LAYOUT_STREAM or GW_LAYOUT_BLOCK");
+    if (gw::pack_genotype_row(begin, end, n_samples, layout == GW_LAYOUT_BLOCK, row) != 0)
+        return fail(GW_E_FORMAT, "genotype row the reference asserts on");
+    return GW_OK;
+}
+
+int gw_build_stream_mask(const int32_t *idx, size_t n_idx, uint32_t n_samples, uint16_t *mask,
+                         uint32_t *count) {
+    if ((!idx && n_idx) || !mask || n_samples == 0) return fail(GW_E_INVALID, "NULL argument");
+    long m = gw::build_stream_mask(idx, n_idx, n_samples, mask);
+    if (m < 0) return fail(GW_E_RANGE, "sample index outside [0, %u)", n_samples);
+    if (count) *count = (uint32_t)m;
+    return GW_OK;
+}
+
+int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    if (missing_q16 > 65535u) return fail(GW_E_INVALID, "missing_q16 must be < 65536");
+    int rc = use_device(t);
+    if (rc) return rc;
+    t->pending_rows = 0;
+    GW_HIP(gw::launch_simulate(t->tv, seed, snp_global_begin, missing_q16, t->compute_units * 8, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    // alleles A (major) / C (minor), all three genotypes: order 7, AA=0, AC=1, CC=5
+    std::fill(t->headers.begin(), t->headers.end(), (uint16_t)0x7015);
+    return GW_OK;
+}
+
+int gw_table_simulate_phenotype(gw_table *t, uint64_t seed) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = use_device(t);
+    if (rc) return rc;
+    GW_HIP(hipMemsetAsync(t->d_misc, 0, 2 * sizeof(uint32_t), t->stream));
+    GW_HIP(gw::launch_simulate_phenotype(seed, t->d_case, t->d_ctrl, t->tv.units, t->tv.n_samples,
+                                         t->d_misc, t->stream));
+    uint32_t counts[2];
+    GW_HIP(hipMemcpyAsync(counts, t->d_misc, sizeof counts, hipMemcpyDeviceToHost, t->stream));
+    const uint32_t nb = t->geo.stream_blocks;
+    t->h_case.assign(nb, 0);
+    t->h_ctrl.assign(nb, 0);
+    // masks back in the reference stream packing: units hold the same bytes
+    const size_t bytes = std::min<size_t>((size_t)nb * 2u, (size_t)t->tv.units * 16u);
+    GW_HIP(hipMemcpyAsync(t->h_case.data(), t->d_case, bytes, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipMemcpyAsync(t->h_ctrl.data(), t->d_ctrl, bytes, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    t->case_count = counts[0];
+    t->ctrl_count = counts[1];
+    t->masks_set = true;
+    return GW_OK;
+}
+
+int gw_table_set_case_control(gw_table *t, const uint16_t *case_stream, const uint16_t *ctrl_stream,
+                              uint32_t n_blocks, uint32_t case_count, uint32_t ctrl_count) {
+    if (!t || !case_stream || !ctrl_stream) return fail(GW_E_INVALID, "NULL argument");
+    if (n_blocks != t->geo.stream_blocks)
+        return fail(GW_E_INVALID, "n_blocks %u: CaseControlSet stream masks of %u samples have %u blocks",
+                    n_blocks, t->geo.n_samples, t->geo.stream_blocks);
+    int rc = use_device(t);
+    if (rc) return rc;
+    t->h_case.assign(case_stream, case_stream + n_blocks);
+    t->h_ctrl.assign(ctrl_stream, ctrl_stream + n_blocks);
+    uint16_t *d_src = reinterpret_cast<uint16_t *>(t->d_staging);
+    GW_HIP(hipMemcpyAsync(d_src, t->h_case.data(), (size_t)n_blocks * 2u, hipMemcpyHostToDevice, t->stream));
+    GW_HIP(hipMemcpyAsync(d_src + n_blocks, t->h_ctrl.data(), (size_t)n_blocks * 2u, hipMemcpyHostToDevice,
+                          t->stream));
+    GW_HIP(gw::launch_mask_in(d_src, n_blocks, t->d_case, t->tv.units, t->tv.n_samples, t->stream));
+    GW_HIP(gw::launch_mask_in(d_src + n_blocks, n_blocks, t->d_ctrl, t->tv.units, t->tv.n_samples, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    t->case_count = case_count;
+    t->ctrl_count = ctrl_count;
+    t->masks_set = true;
+    return GW_OK;
+}
+
+int gw_table_get_case_control(gw_table *t, uint16_t *case_stream, uint16_t *ctrl_stream, uint32_t n_blocks,
+                              uint32_t *case_count, uint32_t *ctrl_count) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    if (!t->masks_set) return fail(GW_E_STATE, "no case/control masks installed");
+    if (n_blocks != t->geo.stream_blocks) return fail(GW_E_INVALID, "n_blocks must be %u", t->geo.stream_blocks);
+    if (case_stream) std::memcpy(case_stream, t->h_case.data(), (size_t)n_blocks * 2u);
+    if (ctrl_stream) std::memcpy(ctrl_stream, t->h_ctrl.data(), (size_t)n_blocks * 2u);
+    if (case_count) *case_count = t->case_count;
+    if (ctrl_count) *ctrl_count = t->ctrl_count;
+    return GW_OK;
+}
+
+// ------------------------------------------------------------------ scans
+
+int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_counts,
+                                void *d_stats, void *hip_stream) {
+    if (!t || (!d_counts && n_snps)) return fail(GW_E_INVALID, "NULL argument");
+    if (!t->masks_set)
+        return fail(GW_E_STATE, "gw_table_set_case_control must be called before a case/control scan");
+    int rc = check_range(t, snp_begin, n_snps);
+    if (rc) return rc;
+    if ((rc = gw_table_flush(t))) return rc;
+    if ((rc = use_device(t))) return rc;
+    const gw::ScanShape sh = scan_shape(t);
+    GW_HIP(gw::launch_scan_cc(t->tv, t->d_case, t->d_ctrl, t->case_count, t->ctrl_count, snp_begin,
+                              (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh,
+                              pick_stream(t, hip_stream)));
+    return GW_OK;
+}
+
+int gw_scan_case_control(gw_table *t, uint64_t snp_begin, uint64_t n_snps, uint32_t *counts, double *stats) {
+    if (!t || (!counts && n_snps)) return fail(GW_E_INVALID, "NULL argument");
+    if (n_snps == 0) return check_range(t, snp_begin, 0);
+    int rc = use_device(t);
+    if (rc) return rc;
+    const size_t b32 = n_snps * GW_N_COUNTS * sizeof(uint32_t), b64 = n_snps * GW_N_STATS * sizeof(double);
+    if ((rc = ensure_scratch(t, b32, stats ? b64 : 0))) return rc;
+    rc = gw_scan_case_control_device(t, snp_begin, n_snps, t->d_scratch32, stats ? t->d_scratch64 : nullptr,
+                                     nullptr);
+    if (rc) return rc;
+    GW_HIP(hipMemcpyAsync(counts, t->d_scratch32, b32, hipMemcpyDeviceToHost, t->stream));
+    if (stats) GW_HIP(hipMemcpyAsync(stats, t->d_scratch64, b64, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    return GW_OK;
+}
+
+int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_dist,
+                                void *hip_stream) {
+    if (!t || (!d_dist && n_snps)) return fail(GW_E_INVALID, "NULL argument");
+    int rc = check_range(t, snp_begin, n_snps);
+    if (rc) return rc;
+    if ((rc = gw_table_flush(t))) return rc;
+    if ((rc = use_device(t))) return rc;
+    GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, t->compute_units,
+                                pick_stream(t, hip_stream)));
+    return GW_OK;
+}
+
+int gw_scan_distribution(gw_table *t, uint64_t snp_begin, uint64_t n_snps, uint32_t *dist) {
+    if (!t || (!dist && n_snps)) return fail(GW_E_INVALID, "NULL argument");
+    if (n_snps == 0) return check_range(t, snp_begin, 0);
+    int rc = use_device(t);
+    if (rc) return rc;
+    const size_t b32 = n_snps * 4 * sizeof(uint32_t);
+    if ((rc = ensure_scratch(t, b32, 0))) return rc;
+    if ((rc = gw_scan_distribution_device(t, snp_begin, n_snps, t->d_scratch32, nullptr))) return rc;
+    GW_HIP(hipMemcpyAsync(dist, t->d_scratch32, b32, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    return GW_OK;
+}
+
+static int pair_common(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, uint32_t *out_a, uint32_t *out_b,
+                       bool masked) {
+    if (!t || ((!pairs || !out_a) && n_pairs) || (masked && !out_b && n_pairs))
+        return fail(GW_E_INVALID, "NULL argument");
+    if (masked && !t->masks_set)
+        return fail(GW_E_STATE, "gw_table_set_case_control must be called before a case/control table");
+    if (n_pairs == 0) return GW_OK;
+    if (n_pairs > 0x0FFFFFFFull) return fail(GW_E_RANGE, "too many pairs in one call");
+    for (uint64_t i = 0; i < 2 * n_pairs; ++i)
+        if (pairs[i] >= t->tv.n_snps) return fail(GW_E_RANGE, "pair %llu names SNP %u outside the table",
+                                                  (unsigned long long)(i / 2), pairs[i]);
+    int rc = gw_table_flush(t);
+    if (rc) return rc;
+    if ((rc = use_device(t))) return rc;
+    const size_t pair_bytes = n_pairs * 2 * sizeof(uint32_t), tab_bytes = n_pairs * 16 * sizeof(uint32_t);
+    if ((rc = ensure_scratch(t, pair_bytes + tab_bytes * (masked ? 2 : 1), 0))) return rc;
+    uint32_t *d_pairs = t->d_scratch32;
+    uint32_t *d_a = d_pairs + n_pairs * 2, *d_b = d_a + n_pairs * 16;
+    GW_HIP(hipMemcpyAsync(d_pairs, pairs, pair_bytes, hipMemcpyHostToDevice, t->stream));
+    const int grid = t->compute_units * 8;
+    if (masked)
+        GW_HIP(gw::launch_pair_cc_contingency(t->tv, t->d_case, t->d_ctrl, d_pairs, (uint32_t)n_pairs, d_a, d_b,
+                                              grid, t->stream));
+    else
+        GW_HIP(gw::launch_pair_contingency(t->tv, d_pairs, (uint32_t)n_pairs, d_a, grid, t->stream));
+    GW_HIP(hipMemcpyAsync(out_a, d_a, tab_bytes, hipMemcpyDeviceToHost, t->stream));
+    if (masked) GW_HIP(hipMemcpyAsync(out_b, d_b, tab_bytes, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    return GW_OK;
+}
+
+int gw_pair_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, uint32_t *out) {
+    return pair_common(t, pairs, n_pairs, out, nullptr, false);
+}
+
+int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, uint32_t *out_case,
+                                     uint32_t *out_ctrl) {
+    return pair_common(t, pairs, n_pairs, out_case, out_ctrl, true);
+}
+
+// ------------------------------------------------------------ measurement
+
+int gw_timer_start(gw_table *t, void *hip_stream) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = use_device(t);
+    if (rc) return rc;
+    GW_HIP(hipEventRecord(t->ev_start, pick_stream(t, hip_stream)));
+    return GW_OK;
+}
+
+int gw_timer_stop(gw_table *t, void *hip_stream, float *elapsed_ms) {
+    if (!t || !elapsed_ms) return fail(GW_E_INVALID, "NULL argument");
+    int rc = use_device(t);
+    if (rc) return rc;
+    GW_HIP(hipEventRecord(t->ev_stop, pick_stream(t, hip_stream)));
+    GW_HIP(hipEventSynchronize(t->ev_stop));
+    GW_HIP(hipEventElapsedTime(elapsed_ms, t->ev_start, t->ev_stop));
+    return GW_OK;
+}
+
+int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = use_device(t);
+    if (rc) return rc;
+    const uint64_t n_units = t->geo.device_table_bytes / 16u;
+    if (n_units)
+        GW_HIP(gw::launch_stream_probe(t->tv.base, n_units, t->d_misc + 8, t->compute_units * 2,
+                                       pick_stream(t, hip_stream)));
+    if (bytes_read) *bytes_read = n_units * 16u;
+    return GW_OK;
+}
+
+int gw_synchronize(gw_table *t) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = use_device(t);
+    if (rc) return rc;
+    GW_HIP(hipStreamSynchronize(t->stream));
+    return GW_OK;
+}
+
+int gw_set_option(gw_table *t, int option, int64_t v) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    switch (option) {
+    case GW_OPT_UNROLL:
+        if (v != 1 && v != 2 && v != 4 && v != 8) return fail(GW_E_INVALID, "unroll must be 1, 2, 4 or 8");
+        t->opt_unroll = (int)v;
+        return GW_OK;
+    case GW_OPT_MASK_IN_LDS:
+        if (v < -1 || v > 1) return fail(GW_E_INVALID, "mask_in_lds must be -1 (auto), 0 or 1");
+        t->opt_mask_lds = (int)v;
+        return GW_OK;
+    case GW_OPT_BLOCKS_PER_CU:
+        if (v < 0 || v > 8) return fail(GW_E_INVALID, "blocks_per_cu must be 0 (auto) .. 8");
+        t->opt_blocks_per_cu = (int)v;
+        return GW_OK;
+    case GW_OPT_NONTEMPORAL:
+        t->opt_nt = v ? 1 : 0;
+        return GW_OK;
+    case GW_OPT_BLOCK_THREADS:
+        if (v != 0 && v != 256 && v != 512 && v != 1024)
+            return fail(GW_E_INVALID, "block_threads must be 0 (auto), 256, 512 or 1024");
+        t->opt_threads = (int)v;
+        return GW_OK;
+    default:
+        return fail(GW_E_INVALID, "unknown option %d", option);
+    }
+}
+
+int gw_get_option(gw_table *t, int option, int64_t *v) {
+    if (!t || !v) return fail(GW_E_INVALID, "NULL argument");
+    const gw::ScanShape sh = scan_shape(t);
+    switch (option) {
+    case GW_OPT_UNROLL: *v = sh.unroll; return GW_OK;
+    case GW_OPT_MASK_IN_LDS: *v = sh.mask_in_lds; return GW_OK;
+    case GW_OPT_BLOCKS_PER_CU: *v = t->compute_units ? sh.grid_blocks / t->compute_units : 0; return GW_OK;
+    case GW_OPT_NONTEMPORAL: *v = sh.nontemporal; return GW_OK;
+    case GW_OPT_BLOCK_THREADS: *v = sh.block_threads; return GW_OK;
+    default: return fail(GW_E_INVALID, "unknown option %d", option);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// gw_kernels.h -- launch interface between the C-ABI (gw_capi.cpp) and the
+// gfx950 kernels (gw_kernels.hip).  Internal; the public surface is
+// include/gwas_scan.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gw {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// HBM layout of the genotype table (DESIGN.md "Data layout in HBM"):
+//   row r        : base + r * row_stride_u            (16-byte units)
+//   plane 0 (lo) : units [0, units)                   bit set for codes 1,3
+//   plane 1 (hi) : units [plane_stride_u, +units)     bit set for codes 2,3
+// sample s lives at bit (s & 127) of unit (s >> 7), little-endian, i.e. the
+// reference's stream packing (table5.cpp:333-344) with the header block moved
+// to a side array and each plane padded to a 128-byte multiple.
+struct TableView {
+    u32x4 *base;
+    uint64_t row_stride_u;
+    uint32_t plane_stride_u;
+    uint32_t units;      // 16-byte units per plane that hold samples
+    uint32_t n_samples;
+    uint64_t n_snps;
+};
+
+struct ScanShape {
+    int unroll;         // units per lane in flight per plane: 1,2,4,8
+    int mask_in_lds;    // stage masks in LDS
+    int nontemporal;    // nt loads on the genotype stream
+    int block_threads;  // 256/512/1024
+    int grid_blocks;    // persistent workgroups
+    size_t lds_bytes;
+};
+
+// case/control scan: counts[n_rows][8], stats[n_rows][8] (stats may be null)
+hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
+                          uint32_t case_count, uint32_t ctrl_count, uint64_t row_begin,
+                          uint32_t n_rows, uint32_t *d_counts, double *d_stats,
+                          const ScanShape &shape, hipStream_t stream);
+// sets hipFuncAttributeMaxDynamicSharedMemorySize on every scan instantiation
+hipError_t prepare_scan_kernels(size_t max_lds_bytes);
+
+// plain distribution: dist[n_rows][4] = aa,ab,bb,xx(exact)
+hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                            uint32_t *d_dist, int grid_blocks, hipStream_t stream);
+
+// pair contingency: pairs[n][2] (row indices), out[n][16]; with masks:
+// out_case/out_ctrl (mask ANDed before decoding, table5.cpp:823-829)
+hipError_t launch_pair_contingency(const TableView &tv, const uint32_t *d_pairs, uint32_t n_pairs,
+                                   uint32_t *d_out, int grid_blocks, hipStream_t stream);
+hipError_t launch_pair_cc_contingency(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
+                                      const uint32_t *d_pairs, uint32_t n_pairs,
+                                      uint32_t *d_out_case, uint32_t *d_out_ctrl, int grid_blocks,
+                                      hipStream_t stream);
+
+// reference packing <-> HBM layout.  src/dst = device staging buffer holding
+// n_rows reference rows `ref_stride_bytes` apart (header block first).
+hipError_t launch_restride_in(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                              const uint8_t *d_src, size_t ref_stride_bytes, int layout,
+                              uint32_t ref_blocks, hipStream_t stream);
+hipError_t launch_restride_out(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                               uint8_t *d_dst, size_t ref_stride_bytes, int layout,
+                               uint32_t ref_blocks, hipStream_t stream);
+// phenotype masks: reference stream packing (uint16 blocks) -> u32x4[units]
+hipError_t launch_mask_in(const uint16_t *d_src, uint32_t n_blocks, u32x4 *d_mask, uint32_t units,
+                          uint32_t n_samples, hipStream_t stream);
+
+// synthetic input (restates data/simulate_data.cpp, see gw_kernels.hip)
+hipError_t launch_simulate(const TableView &tv, uint64_t seed, uint64_t snp_global_begin,
+                           uint32_t missing_q16, int grid_blocks, hipStream_t stream);
+hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl, uint32_t units,
+                                     uint32_t n_samples, uint32_t *d_counts2, hipStream_t stream);
+
+// streaming-read probe over [base, base + n_units): returns a checksum in *d_sink
+hipError_t launch_stream_probe(const u32x4 *base, uint64_t n_units, uint32_t *d_sink,
+                               int grid_blocks, hipStream_t stream);
+
+}  // namespace gw

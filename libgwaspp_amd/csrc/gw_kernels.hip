@@ -1,0 +1,744 @@
+// gw_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-SNP association
+// scan.  Hand-written HIP; no MFMA: this is a popcount / HBM-bandwidth
+// problem (about 0.4 integer ops per byte), so everything here is about
+// 16-byte-per-lane coalesced streaming, enough loads in flight per CU, and
+// keeping the phenotype masks out of the HBM stream.
+//
+// Reference algorithm restated by each kernel (paths relative to
+// /root/reference/src/libgwaspp/):
+//   k_scan_cc    getCaseControlGenotypeDistribution(r, ccs, ccgd)
+//                genotype/compressed_genotype_table5.cpp:609-657, inside the
+//                SNP loop of inline_cc_maf, algorithms/maf_func.cpp:292-316,
+//                + MinorAlleleFrequency, algorithms/maf_func.h:46-54
+//   k_scan_dist  getGenotypeDistribution, table5.cpp:577-607
+//   k_pair*      getContingencyTable / getCaseControlContingencyTable,
+//                table5.cpp:749-800 / 806-895
+//   k_restride*  the row packings of table5.cpp:277-365 / table3.cpp:260-325
+//   k_simulate*  data/simulate_data.cpp:150-235
+#include "gw_kernels.h"
+
+namespace gw {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld_stream(const u32x4 *p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one 16-byte unit of both planes against both masks: 6 running popcounts
+// (table5.cpp:629-646: aa += pc(p0&m), ab += pc(p1&m), bb += pc(p0&p1&m))
+__device__ __forceinline__ void acc_unit(const u32x4 a, const u32x4 b, const u32x4 mc,
+                                         const u32x4 mt, uint32_t (&c)[6]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = a[k] & mc[k], y = b[k] & mc[k];
+        c[0] += __popc(x);
+        c[1] += __popc(y);
+        c[2] += __popc(x & y);
+        x = a[k] & mt[k];
+        y = b[k] & mt[k];
+        c[3] += __popc(x);
+        c[4] += __popc(y);
+        c[5] += __popc(x & y);
+    }
+}
+
+// ---- build-defined statistics (DESIGN.md "Statistics"); the operation order
+// is the oracle's (oracle/gw_oracle.c gwo_assoc_stats), contraction is off.
+__device__ __forceinline__ double ref_maf(double aa, double ab, double bb) {
+    // MinorAlleleFrequency, algorithms/maf_func.h:46-54 (quirk Q5 kept)
+    double t = aa;
+    double m = 2.0 * t;
+    t += ab;
+    m += ab;
+    t += bb;
+    m /= t;
+    if (m < 0.5) m = 1.0 - m;
+    return m;
+}
+
+__device__ __forceinline__ double hwe_chi2(double aa, double ab, double bb) {
+    double n = aa + ab + bb;
+    if (n <= 0.0) return 0.0;
+    double p = (2.0 * aa + ab) / (2.0 * n);
+    double q = 1.0 - p;
+    double e0 = n * p * p, e1 = 2.0 * n * p * q, e2 = n * q * q;
+    double x = 0.0, d;
+    if (e0 > 0.0) { d = aa - e0; x += d * d / e0; }
+    if (e1 > 0.0) { d = ab - e1; x += d * d / e1; }
+    if (e2 > 0.0) { d = bb - e2; x += d * d / e2; }
+    return x;
+}
+
+__device__ __forceinline__ void assoc_stats(const uint32_t ca[4], const uint32_t co[4],
+                                            double *out) {
+    const double caa = ca[0], cab = ca[1], cbb = ca[2];
+    const double taa = co[0], tab = co[1], tbb = co[2];
+    const double r1 = caa + cab + cbb, r2 = taa + tab + tbb, n = r1 + r2;
+    out[0] = (r1 > 0.0) ? ref_maf(caa, cab, cbb) : 0.0;
+    out[1] = (r2 > 0.0) ? ref_maf(taa, tab, tbb) : 0.0;
+    if (n > 0.0) {
+        double p = (2.0 * (caa + taa) + (cab + tab)) / (2.0 * n);
+        out[2] = (p > 0.5) ? 1.0 - p : p;
+    } else {
+        out[2] = 0.0;
+    }
+    out[3] = hwe_chi2(taa, tab, tbb);
+    out[4] = hwe_chi2(caa + taa, cab + tab, cbb + tbb);
+    {
+        const double o[2][3] = {{caa, cab, cbb}, {taa, tab, tbb}};
+        const double r[2] = {r1, r2};
+        const double c[3] = {caa + taa, cab + tab, cbb + tbb};
+        double x = 0.0;
+        if (n > 0.0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double e = r[i] * c[j] / n;
+                    if (e > 0.0) { double d = o[i][j] - e; x += d * d / e; }
+                }
+        }
+        out[5] = x;
+    }
+    {
+        double a = 2.0 * caa + cab, b = 2.0 * cbb + cab;
+        double c = 2.0 * taa + tab, d = 2.0 * tbb + tab;
+        double den = (a + b) * (c + d) * (a + c) * (b + d);
+        double det = a * d - b * c;
+        out[6] = (den > 0.0) ? (a + b + c + d) * det * det / den : 0.0;
+    }
+    {
+        double members = r1 + (double)ca[3] + r2 + (double)co[3];
+        out[7] = (members > 0.0) ? n / members : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the scan: one wavefront owns one SNP row at a time
+// ---------------------------------------------------------------------------
+
+struct ScanArgs {
+    const u32x4 *table;
+    uint64_t row_stride_u;
+    uint32_t plane_stride_u;
+    uint32_t units;
+    const u32x4 *case_mask;
+    const u32x4 *ctrl_mask;
+    uint64_t row_begin;
+    uint32_t n_rows;
+    uint32_t case_count, ctrl_count;
+    uint32_t *counts;
+    double *stats;
+};
+
+// Persistent workgroups: the grid is (CUs x workgroups-per-CU); each wave
+// walks rows gwave, gwave + total_waves, ...  Per row a lane streams 16-byte
+// units lane, lane+64, ... of both bit-planes (two 1-KiB coalesced
+// wave-loads per step, UNROLL steps in flight), ANDs them with the case and
+// control masks (staged once per workgroup in LDS, or read through L2 when
+// they do not fit) and keeps six 32-bit popcounts; a wave-level shuffle
+// reduction and lane 0's FP64 epilogue finish the row.
+template <int UNROLL, bool MASK_LDS, bool NT>
+__global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
+    extern __shared__ u32x4 lds_masks[];  // [2][units] when MASK_LDS
+    const uint32_t units = a.units;
+    const u32x4 *mcase = a.case_mask;
+    const u32x4 *mctrl = a.ctrl_mask;
+    if (MASK_LDS) {
+        for (uint32_t u = threadIdx.x; u < units; u += blockDim.x) {
+            lds_masks[u] = a.case_mask[u];
+            lds_masks[units + u] = a.ctrl_mask[u];
+        }
+        __syncthreads();
+        mcase = lds_masks;
+        mctrl = lds_masks + units;
+    }
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    constexpr uint32_t STEP = 64u * UNROLL;
+    const uint32_t full = (units / STEP) * STEP;
+
+    for (uint32_t r = gwave; r < a.n_rows; r += total_waves) {
+        const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
+        const u32x4 *p1 = p0 + a.plane_stride_u;
+        uint32_t c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+
+        for (uint32_t base = 0; base < full; base += STEP) {
+            u32x4 A[UNROLL], B[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                A[k] = ld_stream<NT>(p0 + base + 64u * k + lane);
+                B[k] = ld_stream<NT>(p1 + base + 64u * k + lane);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const u32x4 mc = mcase[base + 64u * k + lane];
+                const u32x4 mt = mctrl[base + 64u * k + lane];
+                if (k & 1) acc_unit(A[k], B[k], mc, mt, c1);
+                else acc_unit(A[k], B[k], mc, mt, c0);
+            }
+        }
+        for (uint32_t u = full + lane; u < units; u += 64u) {
+            const u32x4 A = ld_stream<NT>(p0 + u), B = ld_stream<NT>(p1 + u);
+            acc_unit(A, B, mcase[u], mctrl[u], c0);
+        }
+
+        uint32_t s[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s[j] = wave_sum(c0[j] + c1[j]);
+
+        if (lane == 0) {
+            // table5.cpp:647-653
+            uint32_t ca[4], co[4];
+            ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
+            ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
+            co[2] = s[5]; co[0] = s[3] - s[5]; co[1] = s[4] - s[5];
+            co[3] = a.ctrl_count - co[0] - co[1] - co[2];
+            u32x4 *out = reinterpret_cast<u32x4 *>(a.counts + (size_t)r * 8u);
+            u32x4 v0 = {ca[0], ca[1], ca[2], ca[3]};
+            u32x4 v1 = {co[0], co[1], co[2], co[3]};
+            out[0] = v0;
+            out[1] = v1;
+            if (a.stats) {
+                double st[8];
+                assoc_stats(ca, co, st);
+                double *so = a.stats + (size_t)r * 8u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) so[j] = st[j];
+            }
+        }
+    }
+}
+
+template <int UNROLL, bool MASK_LDS, bool NT>
+static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
+    hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
+                       dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
+    return hipGetLastError();
+}
+
+template <int UNROLL>
+static hipError_t launch_scan_u(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
+    if (sh.mask_in_lds) {
+        return sh.nontemporal ? launch_scan_inst<UNROLL, true, true>(args, sh, stream)
+                              : launch_scan_inst<UNROLL, true, false>(args, sh, stream);
+    }
+    return sh.nontemporal ? launch_scan_inst<UNROLL, false, true>(args, sh, stream)
+                          : launch_scan_inst<UNROLL, false, false>(args, sh, stream);
+}
+
+hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
+                          uint32_t case_count, uint32_t ctrl_count, uint64_t row_begin,
+                          uint32_t n_rows, uint32_t *d_counts, double *d_stats,
+                          const ScanShape &sh, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    ScanArgs a;
+    a.table = tv.base;
+    a.row_stride_u = tv.row_stride_u;
+    a.plane_stride_u = tv.plane_stride_u;
+    a.units = tv.units;
+    a.case_mask = d_case;
+    a.ctrl_mask = d_ctrl;
+    a.row_begin = row_begin;
+    a.n_rows = n_rows;
+    a.case_count = case_count;
+    a.ctrl_count = ctrl_count;
+    a.counts = d_counts;
+    a.stats = d_stats;
+    switch (sh.unroll) {
+    case 1: return launch_scan_u<1>(a, sh, stream);
+    case 2: return launch_scan_u<2>(a, sh, stream);
+    case 8: return launch_scan_u<8>(a, sh, stream);
+    default: return launch_scan_u<4>(a, sh, stream);
+    }
+}
+
+template <int UNROLL>
+static hipError_t prepare_u(size_t bytes) {
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t prepare_scan_kernels(size_t max_lds_bytes) {
+    hipError_t e;
+    if ((e = prepare_u<1>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = prepare_u<2>(max_lds_bytes)) != hipSuccess) return e;
+    if ((e = prepare_u<4>(max_lds_bytes)) != hipSuccess) return e;
+    return prepare_u<8>(max_lds_bytes);
+}
+
+// ---------------------------------------------------------------------------
+// plain genotype distribution (no masks), table5.cpp:577-607
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_scan_dist(const u32x4 *table, uint64_t row_stride_u,
+                                                    uint32_t plane_stride_u, uint32_t units,
+                                                    uint32_t n_samples, uint64_t row_begin,
+                                                    uint32_t n_rows, uint32_t *dist) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    constexpr uint32_t STEP = 256u;
+    const uint32_t full = (units / STEP) * STEP;
+    for (uint32_t r = gwave; r < n_rows; r += total_waves) {
+        const u32x4 *p0 = table + (row_begin + r) * row_stride_u;
+        const u32x4 *p1 = p0 + plane_stride_u;
+        uint32_t c[3] = {0, 0, 0};
+        for (uint32_t base = 0; base < full; base += STEP) {
+            u32x4 A[4], B[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                A[k] = ld_stream<true>(p0 + base + 64u * k + lane);
+                B[k] = ld_stream<true>(p1 + base + 64u * k + lane);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c[0] += __popc(A[k][j]);
+                    c[1] += __popc(B[k][j]);
+                    c[2] += __popc(A[k][j] & B[k][j]);
+                }
+        }
+        for (uint32_t u = full + lane; u < units; u += 64u) {
+            const u32x4 A = ld_stream<true>(p0 + u), B = ld_stream<true>(p1 + u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[0] += __popc(A[j]);
+                c[1] += __popc(B[j]);
+                c[2] += __popc(A[j] & B[j]);
+            }
+        }
+        const uint32_t s0 = wave_sum(c[0]), s1 = wave_sum(c[1]), s2 = wave_sum(c[2]);
+        if (lane == 0) {
+            const uint32_t aa = s0 - s2, ab = s1 - s2, bb = s2;
+            u32x4 v = {aa, ab, bb, n_samples - aa - ab - bb};
+            *reinterpret_cast<u32x4 *>(dist + (size_t)r * 4u) = v;
+        }
+    }
+}
+
+hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                            uint32_t *d_dist, int grid_blocks, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_dist, dim3(grid_blocks), dim3(1024), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, tv.n_samples, row_begin,
+                       n_rows, d_dist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// pairwise 4x4 contingency for a list of SNP pairs: one wave per pair.
+// (first correct form; the LDS-tiled all-pairs kernel of BASELINE config 5 is
+// the NEXT row)
+// ---------------------------------------------------------------------------
+// classes of one 32-bit word: [aa, ab, bb, xx] (DecodeBitStreams2BitStream,
+// compressed_genotype_table5.h:104-115)
+__device__ __forceinline__ void decode32(uint32_t p0, uint32_t p1, uint32_t (&cls)[4]) {
+    cls[3] = ~(p0 | p1);
+    cls[2] = p0 & p1;
+    cls[0] = p0 ^ cls[2];
+    cls[1] = p1 ^ cls[2];
+}
+
+template <bool MASKED>
+__global__ void __launch_bounds__(256) k_pair(const u32x4 *table, uint64_t row_stride_u,
+                                              uint32_t plane_stride_u, uint32_t units,
+                                              uint32_t ref_words, const u32x4 *mcase,
+                                              const u32x4 *mctrl, const uint32_t *pairs,
+                                              uint32_t n_pairs, uint32_t *out_a, uint32_t *out_b) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    for (uint32_t p = gwave; p < n_pairs; p += total_waves) {
+        const u32x4 *a0 = table + (uint64_t)pairs[2 * p] * row_stride_u;
+        const u32x4 *b0 = table + (uint64_t)pairs[2 * p + 1] * row_stride_u;
+        uint32_t ca[16], cb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ca[i] = 0; cb[i] = 0; }
+        for (uint32_t u = lane; u < units; u += 64u) {
+            const u32x4 A0 = a0[u], A1 = a0[plane_stride_u + u];
+            const u32x4 B0 = b0[u], B1 = b0[plane_stride_u + u];
+            u32x4 MC, MT;
+            if (MASKED) { MC = mcase[u]; MT = mctrl[u]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // the reference walks gbo/4 64-bit words; the HBM row may hold
+                // one more (all-zero) word, which must not count as xx_xx
+                if (2u * u + (uint32_t)(k >> 1) >= ref_words) continue;
+                uint32_t x[4], y[4];
+                if (MASKED) {
+                    decode32(A0[k] & MC[k], A1[k] & MC[k], x);
+                    decode32(B0[k] & MC[k], B1[k] & MC[k], y);
+                } else {
+                    decode32(A0[k], A1[k], x);
+                    decode32(B0[k], B1[k], y);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ca[4 * i + j] += __popc(x[i] & y[j]);
+                if (MASKED) {
+                    decode32(A0[k] & MT[k], A1[k] & MT[k], x);
+                    decode32(B0[k] & MT[k], B1[k] & MT[k], y);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cb[4 * i + j] += __popc(x[i] & y[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t s = wave_sum(ca[i]);
+            if (lane == 0) out_a[(size_t)p * 16u + i] = s;
+            if (MASKED) {
+                s = wave_sum(cb[i]);
+                if (lane == 0) out_b[(size_t)p * 16u + i] = s;
+            }
+        }
+    }
+}
+
+static uint32_t ref_stream_words(uint32_t n_samples) {
+    uint32_t blocks = n_samples / 16u + 1u;
+    blocks = (blocks + 3u) & ~3u;
+    return blocks / 4u;
+}
+
+hipError_t launch_pair_contingency(const TableView &tv, const uint32_t *d_pairs, uint32_t n_pairs,
+                                   uint32_t *d_out, int grid_blocks, hipStream_t stream) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair<false>, dim3(grid_blocks), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, ref_stream_words(tv.n_samples),
+                       (const u32x4 *)nullptr, (const u32x4 *)nullptr, d_pairs, n_pairs, d_out,
+                       (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_cc_contingency(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
+                                      const uint32_t *d_pairs, uint32_t n_pairs,
+                                      uint32_t *d_out_case, uint32_t *d_out_ctrl, int grid_blocks,
+                                      hipStream_t stream) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pair<true>, dim3(grid_blocks), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, ref_stream_words(tv.n_samples),
+                       d_case, d_ctrl, d_pairs, n_pairs, d_out_case, d_out_ctrl);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// reference packings <-> HBM layout
+// ---------------------------------------------------------------------------
+
+// gather the even bits of v into the low 16 bits
+__device__ __forceinline__ uint32_t even_bits(uint32_t v) {
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+// spread the low 16 bits of v to the even bit positions
+__device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
+    v &= 0x0000FFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// one workgroup per row (grid-strided), threads over the row's 16-byte units
+__global__ void __launch_bounds__(256) k_restride_in(u32x4 *table, uint64_t row_stride_u,
+                                                     uint32_t plane_stride_u, uint64_t row_begin,
+                                                     uint32_t n_rows, const uint8_t *src,
+                                                     size_t ref_stride, int block_layout,
+                                                     uint32_t ref_blocks) {
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(src + (size_t)r * ref_stride) + 1;
+        u32x4 *d0 = table + (row_begin + r) * row_stride_u;
+        u32x4 *d1 = d0 + plane_stride_u;
+        for (uint32_t u = threadIdx.x; u < plane_stride_u; u += blockDim.x) {
+            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (!block_layout) {
+                // stream packing: plane p block i at row[p*ref_blocks + i]; 8 blocks per unit
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t i = 8u * u + j;
+                    if (i < ref_blocks) {
+                        lo[j >> 1] |= (uint32_t)row[i] << (16 * (j & 1));
+                        hi[j >> 1] |= (uint32_t)row[ref_blocks + i] << (16 * (j & 1));
+                    }
+                }
+            } else {
+                // block packing: 8 samples x 2 bits per block; 16 blocks per unit;
+                // low bit -> plane 0, high bit -> plane 1 (codes 1,3 / 2,3)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t i = 16u * u + j;
+                    if (i < ref_blocks) {
+                        const uint32_t v = row[i];
+                        lo[j >> 2] |= even_bits(v) << (8 * (j & 3));
+                        hi[j >> 2] |= even_bits(v >> 1) << (8 * (j & 3));
+                    }
+                }
+            }
+            d0[u] = lo;
+            d1[u] = hi;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_restride_out(const u32x4 *table, uint64_t row_stride_u,
+                                                      uint32_t plane_stride_u, uint32_t units,
+                                                      uint64_t row_begin, uint32_t n_rows,
+                                                      uint8_t *dst, size_t ref_stride,
+                                                      int block_layout, uint32_t ref_blocks) {
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        uint16_t *row = reinterpret_cast<uint16_t *>(dst + (size_t)r * ref_stride) + 1;
+        const u32x4 *s0 = table + (row_begin + r) * row_stride_u;
+        const u32x4 *s1 = s0 + plane_stride_u;
+        if (threadIdx.x == 0) row[-1] = 0;  // header: filled in by the host
+        const uint32_t per_unit = block_layout ? 16u : 8u;
+        const uint32_t need = (ref_blocks + per_unit - 1u) / per_unit;
+        for (uint32_t u = threadIdx.x; u < need; u += blockDim.x) {
+            u32x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (u < units) { lo = s0[u]; hi = s1[u]; }
+            if (!block_layout) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t i = 8u * u + j;
+                    if (i < ref_blocks) {
+                        row[i] = (uint16_t)(lo[j >> 1] >> (16 * (j & 1)));
+                        row[ref_blocks + i] = (uint16_t)(hi[j >> 1] >> (16 * (j & 1)));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t i = 16u * u + j;
+                    if (i < ref_blocks) {
+                        const uint32_t l8 = (lo[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        const uint32_t h8 = (hi[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        row[i] = (uint16_t)(spread_bits(l8) | (spread_bits(h8) << 1));
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int small_grid(uint32_t n_rows) { return (int)(n_rows < 4096u ? n_rows : 4096u); }
+
+hipError_t launch_restride_in(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                              const uint8_t *d_src, size_t ref_stride_bytes, int layout,
+                              uint32_t ref_blocks, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_restride_in, dim3(small_grid(n_rows)), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, row_begin, n_rows, d_src,
+                       ref_stride_bytes, layout == 3 ? 1 : 0, ref_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_restride_out(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
+                               uint8_t *d_dst, size_t ref_stride_bytes, int layout,
+                               uint32_t ref_blocks, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_restride_out, dim3(small_grid(n_rows)), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, row_begin, n_rows, d_dst,
+                       ref_stride_bytes, layout == 3 ? 1 : 0, ref_blocks);
+    return hipGetLastError();
+}
+
+__global__ void k_mask_in(const uint16_t *src, uint32_t n_blocks, u32x4 *mask, uint32_t units) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    u32x4 m = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t i = 8u * u + j;
+        if (i < n_blocks) m[j >> 1] |= (uint32_t)src[i] << (16 * (j & 1));
+    }
+    mask[u] = m;
+}
+
+hipError_t launch_mask_in(const uint16_t *d_src, uint32_t n_blocks, u32x4 *d_mask, uint32_t units,
+                          uint32_t n_samples, hipStream_t stream) {
+    (void)n_samples;
+    hipLaunchKernelGGL(k_mask_in, dim3((units + 255u) / 256u), dim3(256), 0, stream, d_src,
+                       n_blocks, d_mask, units);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// synthetic input: data/simulate_data.cpp:150-235 restated with a
+// counter-based generator (same constants and draw order as
+// oracle/gw_oracle.c gwo_sim_*; DESIGN.md "Synthetic input")
+// ---------------------------------------------------------------------------
+__device__ __constant__ uint32_t k_affy6[51] = {
+    // affy6 column of data/maf_spectrum.tab, MAF bins 0.00 .. 0.50
+    23486, 18503, 16090, 16751, 15610, 33044, 17674, 16029, 16403, 15372, 29748, 16045, 14741,
+    14874, 13997, 27101, 15027, 13233, 14199, 12800, 25738, 13828, 13188, 13368, 12272, 24398,
+    12968, 12653, 12657, 11557, 23319, 12626, 11183, 12830, 11411, 22332, 11922, 10943, 12225,
+    10944, 21966, 11463, 10873, 11675, 11194, 21596, 11478, 10541, 11511, 10658, 6014};
+#define K_AFFY6_TOTAL 792058ull
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+#define SIM_SNP_MUL 0x632BE59BD9B4E019ull
+#define SIM_WORD_MUL 0xD1342543DE82EF95ull
+#define SIM_DRAW_MUL 0xA0761D6478BD642Full
+#define SIM_PHENO_TAG 0x00CA5EC0117201ull
+
+__device__ __forceinline__ uint64_t bernoulli64(uint64_t key, uint32_t base, uint32_t thr) {
+    uint64_t lt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t r = splitmix64(key + SIM_DRAW_MUL * (uint64_t)(base + k + 1));
+        lt = ((thr >> k) & 1u) ? (lt | r) : (lt & r);
+    }
+    return lt;
+}
+
+__device__ __forceinline__ uint64_t valid_bits(uint32_t word, uint32_t n_samples) {
+    const uint64_t first = (uint64_t)word * 64ull;
+    if (first >= n_samples) return 0ull;
+    const uint64_t left = n_samples - first;
+    return left >= 64ull ? ~0ull : ((1ull << left) - 1ull);
+}
+
+__global__ void __launch_bounds__(256) k_simulate(u32x4 *table, uint64_t row_stride_u,
+                                                  uint32_t plane_stride_u, uint32_t n_samples,
+                                                  uint64_t n_rows, uint64_t seed, uint64_t snp0,
+                                                  uint32_t missing_q16) {
+    for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        // simulate_data.cpp:176-192: MAF bin ~ spectrum, p = bin/100 + U{0..999}/1e5
+        const uint64_t key = splitmix64(seed + SIM_SNP_MUL * (snp0 + r + 1));
+        uint64_t pick = splitmix64(key ^ 1u) % K_AFFY6_TOTAL;
+        uint32_t bin = 0;
+        while (pick >= k_affy6[bin]) { pick -= k_affy6[bin]; ++bin; }
+        const uint32_t p_e5 = bin * 1000u + (uint32_t)(splitmix64(key ^ 2u) % 1000u);
+        const uint32_t thr = (uint32_t)(((uint64_t)p_e5 * 65536ull) / 100000ull);
+        u32x4 *d0 = table + r * row_stride_u;
+        u32x4 *d1 = d0 + plane_stride_u;
+        for (uint32_t u = threadIdx.x; u < plane_stride_u; u += blockDim.x) {
+            uint64_t a[2], b[2];
+#pragma unroll
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t w = 2u * u + h;
+                const uint64_t valid = valid_bits(w, n_samples);
+                a[h] = 0; b[h] = 0;
+                if (valid) {
+                    const uint64_t wkey = key + SIM_WORD_MUL * (uint64_t)(w + 1);
+                    const uint64_t m1 = bernoulli64(wkey, 0, thr);
+                    const uint64_t m2 = bernoulli64(wkey, 16, thr);
+                    uint64_t x = ~(m1 ^ m2), y = m1 | m2;
+                    if (missing_q16) {
+                        const uint64_t miss = bernoulli64(wkey, 32, missing_q16);
+                        x &= ~miss;
+                        y &= ~miss;
+                    }
+                    a[h] = x & valid;
+                    b[h] = y & valid;
+                }
+            }
+            u32x4 lo = {(uint32_t)a[0], (uint32_t)(a[0] >> 32), (uint32_t)a[1], (uint32_t)(a[1] >> 32)};
+            u32x4 hi = {(uint32_t)b[0], (uint32_t)(b[0] >> 32), (uint32_t)b[1], (uint32_t)(b[1] >> 32)};
+            d0[u] = lo;
+            d1[u] = hi;
+        }
+    }
+}
+
+hipError_t launch_simulate(const TableView &tv, uint64_t seed, uint64_t snp_global_begin,
+                           uint32_t missing_q16, int grid_blocks, hipStream_t stream) {
+    if (tv.n_snps == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_simulate, dim3(grid_blocks), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.n_samples, tv.n_snps, seed,
+                       snp_global_begin, missing_q16);
+    return hipGetLastError();
+}
+
+// simulate_data.cpp:219-235: fair coin per sample, 1 = case, 0 = control
+__global__ void k_simulate_phenotype(uint64_t seed, u32x4 *mcase, u32x4 *mctrl, uint32_t units,
+                                     uint32_t n_samples, uint32_t *counts2) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    uint64_t c[2], t[2];
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        const uint32_t w = 2u * u + h;
+        const uint64_t coin = splitmix64((seed ^ SIM_PHENO_TAG) + SIM_WORD_MUL * (uint64_t)(w + 1));
+        const uint64_t valid = valid_bits(w, n_samples);
+        c[h] = coin & valid;
+        t[h] = ~coin & valid;
+    }
+    u32x4 vc = {(uint32_t)c[0], (uint32_t)(c[0] >> 32), (uint32_t)c[1], (uint32_t)(c[1] >> 32)};
+    u32x4 vt = {(uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)t[1], (uint32_t)(t[1] >> 32)};
+    mcase[u] = vc;
+    mctrl[u] = vt;
+    atomicAdd(&counts2[0], (uint32_t)(__popcll(c[0]) + __popcll(c[1])));
+    atomicAdd(&counts2[1], (uint32_t)(__popcll(t[0]) + __popcll(t[1])));
+}
+
+hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl, uint32_t units,
+                                     uint32_t n_samples, uint32_t *d_counts2, hipStream_t stream) {
+    hipLaunchKernelGGL(k_simulate_phenotype, dim3((units + 255u) / 256u), dim3(256), 0, stream,
+                       seed, d_case, d_ctrl, units, n_samples, d_counts2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// streaming-read probe: the empirical HBM read ceiling on this very buffer
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_stream_probe(const u32x4 *base, uint64_t n_units,
+                                                       uint32_t *sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; i + 3ull * stride < n_units; i += 4ull * stride) {
+        const u32x4 v0 = ld_stream<true>(base + i), v1 = ld_stream<true>(base + i + stride);
+        const u32x4 v2 = ld_stream<true>(base + i + 2ull * stride);
+        const u32x4 v3 = ld_stream<true>(base + i + 3ull * stride);
+        acc ^= v0 ^ v1 ^ v2 ^ v3;
+    }
+    for (; i < n_units; i += stride) acc ^= ld_stream<true>(base + i);
+    uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if ((threadIdx.x & 63u) == 0 && x == 0xDEADBEEFu) atomicAdd(sink, 1u);
+}
+
+hipError_t launch_stream_probe(const u32x4 *base, uint64_t n_units, uint32_t *d_sink,
+                               int grid_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_stream_probe, dim3(grid_blocks), dim3(1024), 0, stream, base, n_units,
+                       d_sink);
+    return hipGetLastError();
+}
+
+}  // namespace gw

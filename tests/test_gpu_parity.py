@@ -1,0 +1,284 @@
+"""Parity of the HIP path (through the C-ABI, libgwaspp_amd/libgwscan.so) with
+the CPU oracle and with the reference's golden files.  Integer counts are
+bit-exact; FP64 statistics within rel 1e-10 (BASELINE.json north_star).
+Needs a real MI355X: pytest -m gpu."""
+import numpy as np
+import pytest
+
+import libgwaspp_amd as gw
+from libgwaspp_amd import capi
+from golden_util import (expected_in_table_space, golden_sets, read_dist, read_tfam_status,
+                         read_tped)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10   # north_star: double-precision chi-square within 1e-10 of the CPU path
+ATOL = 1e-12
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if gw.device_count() == 0:
+        pytest.fail("no HIP device visible: the gpu tests must run on the GPU box "
+                    "(the product has no CPU fallback)")
+
+
+def _assert_stats(got, want):
+    assert got.shape == want.shape
+    assert np.all(np.isfinite(got))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def _random_codes(rng, m, n, p_missing=0.02):
+    """codes in table space; row r has its own allele frequency."""
+    q = rng.uniform(0.02, 0.5, size=(m, 1))
+    a = rng.random((m, n)) < q
+    b = rng.random((m, n)) < q
+    codes = np.where(a & b, 3, np.where(a | b, 2, 1)).astype(np.uint8)
+    codes[rng.random((m, n)) < p_missing] = 0
+    return codes
+
+
+def _random_masks(oracle, rng, n, p_case=0.45, p_ctrl=0.45):
+    u = rng.random(n)
+    cases = np.flatnonzero(u < p_case).astype(np.int32)
+    ctrls = np.flatnonzero((u >= p_case) & (u < p_case + p_ctrl)).astype(np.int32)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    return cs, ct, nc, nt
+
+
+# --------------------------------------------------------------------------
+# the reference's golden files, end to end through the drop-in boundary
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_sets("cc"))
+def test_golden_case_control(oracle, name):
+    n = int(name.split("_n")[1])
+    lines = read_tped(name)
+    exp_case, exp_ctrl = read_dist(name, "case.dist"), read_dist(name, "control.dist")
+    cases, ctrls = read_tfam_status(name)
+    cs, nc = gw.build_stream_mask(cases, n)
+    ct, nt = gw.build_stream_mask(ctrls, n)
+    with gw.GwTable(n, len(lines)) as t:
+        for r, ln in enumerate(lines):
+            t.add_genotype_row(r, oracle.tped_genotype_text(ln))
+        t.set_case_control(cs, ct, nc, nt)
+        counts, stats = t.scan_case_control()
+        for r, ln in enumerate(lines):
+            want = expected_in_table_space(exp_case[r], ln) + expected_in_table_space(exp_ctrl[r], ln)
+            assert tuple(int(v) for v in counts[r]) == want
+            _assert_stats(stats[r], oracle.assoc_stats(want[:4], want[4:]))
+
+
+@pytest.mark.parametrize("name", golden_sets("plain"))
+def test_golden_distribution(oracle, name):
+    n = int(name.split("_n")[1])
+    lines = read_tped(name)
+    exp = read_dist(name, "dist")
+    with gw.GwTable(n, len(lines)) as t:
+        for r, ln in enumerate(lines):
+            t.add_genotype_row(r, oracle.tped_genotype_text(ln))
+        dist = t.scan_distribution()
+        hdr = t.headers(0, len(lines))
+        ref_rows = oracle.pack_rows([oracle.tped_genotype_text(ln) for ln in lines], n)
+        assert np.array_equal(hdr, ref_rows[:, 0])
+        for r, ln in enumerate(lines):
+            assert tuple(int(v) for v in dist[r]) == expected_in_table_space(exp[r], ln)
+        # everyone a case: the cc scan returns the same counts (25 % missing here)
+        allm, cnt = gw.build_stream_mask(np.arange(n, dtype=np.int32), n)
+        none, _ = gw.build_stream_mask([], n)
+        t.set_case_control(allm, none, cnt, 0)
+        counts, _ = t.scan_case_control()
+        assert np.array_equal(counts[:, :4], dist) and not counts[:, 4:].any()
+
+
+# --------------------------------------------------------------------------
+# seeded random inputs vs the oracle, every kernel shape
+# --------------------------------------------------------------------------
+SIZES = [(1, 5), (63, 40), (64, 40), (65, 40), (127, 33), (128, 33), (129, 33), (1000, 300),
+         (4097, 257), (8192, 64), (10_000, 500), (100_003, 40)]
+
+
+@pytest.mark.parametrize("n,m", SIZES)
+def test_random_vs_oracle_both_layouts(oracle, n, m):
+    rng = np.random.default_rng(1000 + n)
+    codes = _random_codes(rng, m, n)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    gs = oracle.geometry_stream(n)
+    ts = oracle.pack_codes(codes, "stream")
+    tb = oracle.pack_codes(codes, "block")
+    want_counts, want_stats = oracle.scan_stream_cc(ts, gs, cs, ct, nc, nt)
+    bm_c, _, _ = oracle.ccs_masks(np.flatnonzero(np.unpackbits(cs.view(np.uint8), bitorder="little")[:n]), n)
+    bm_t, _, _ = oracle.ccs_masks(np.flatnonzero(np.unpackbits(ct.view(np.uint8), bitorder="little")[:n]), n)
+    # the reference's two layouts agree with each other
+    cb, _ = oracle.scan_block_cc(tb, oracle.geometry_block(n), bm_c, bm_t, nc, nt)
+    assert np.array_equal(cb, want_counts)
+    for layout, table in ((gw.LAYOUT_STREAM, ts), (gw.LAYOUT_BLOCK, tb)):
+        with gw.GwTable(n, m) as t:
+            t.upload_rows(0, table, layout)
+            t.set_case_control(cs, ct, nc, nt)
+            counts, stats = t.scan_case_control()
+            assert np.array_equal(counts, want_counts)
+            _assert_stats(stats, want_stats)
+            # counts-only form
+            c2, s2 = t.scan_case_control(stats=False)
+            assert s2 is None and np.array_equal(c2, want_counts)
+            # sub-range
+            if m > 7:
+                c3, s3 = t.scan_case_control(3, m - 7)
+                assert np.array_equal(c3, want_counts[3:m - 4]) and np.array_equal(s3, stats[3:m - 4])
+            # plain distribution, exact xx
+            dist = t.scan_distribution()
+            for r in (0, m // 2, m - 1):
+                aa, ab, bb, xx = oracle.stream_dist(ts[r], gs)
+                assert tuple(int(v) for v in dist[r]) == (aa, ab, bb, n - aa - ab - bb)
+            # round trip in both reference packings
+            assert np.array_equal(t.download_rows(0, m, gw.LAYOUT_STREAM), ts)
+            assert np.array_equal(t.download_rows(0, m, gw.LAYOUT_BLOCK), tb)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 700), (20_000, 1200), (70_001, 300)])
+def test_every_kernel_shape_gives_identical_results(oracle, n, m):
+    rng = np.random.default_rng(77 + n)
+    codes = _random_codes(rng, m, n)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    ts = oracle.pack_codes(codes, "stream")
+    want_counts, want_stats = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs, ct, nc, nt)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        for unroll in (1, 2, 4, 8):
+            for lds in (0, 1):
+                for nt_loads in (0, 1):
+                    for threads, per_cu in ((256, 4), (512, 2), (1024, 1), (0, 0)):
+                        t.set_option(capi.OPT_UNROLL, unroll)
+                        t.set_option(capi.OPT_MASK_IN_LDS, lds)
+                        t.set_option(capi.OPT_NONTEMPORAL, nt_loads)
+                        t.set_option(capi.OPT_BLOCK_THREADS, threads)
+                        t.set_option(capi.OPT_BLOCKS_PER_CU, per_cu)
+                        counts, stats = t.scan_case_control()
+                        assert np.array_equal(counts, want_counts), (unroll, lds, nt_loads, threads)
+                        _assert_stats(stats, want_stats)
+
+
+def test_mask_edge_cases(oracle):
+    n, m = 3001, 50
+    rng = np.random.default_rng(9)
+    codes = _random_codes(rng, m, n, p_missing=0.1)
+    ts = oracle.pack_codes(codes, "stream")
+    gs = oracle.geometry_stream(n)
+    everyone = np.arange(n, dtype=np.int32)
+    cases = everyone[::3]
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        with pytest.raises(gw.GwError) as e:   # scan before the masks are installed
+            t.scan_case_control()
+        assert e.value.code == -4
+        combos = {
+            "empty": (np.zeros(0, np.int32), np.zeros(0, np.int32)),
+            "all cases": (everyone, np.zeros(0, np.int32)),
+            "all controls": (np.zeros(0, np.int32), everyone),
+            "neither for most": (cases[:5], everyone[1:2]),
+            # a sample in both sets: the inline path applies the two masks independently
+            "overlap": (everyone[: n // 2 + 100], everyone[n // 2 - 100:]),
+        }
+        for label, (ca, co) in combos.items():
+            _, cs, nc = oracle.ccs_masks(ca, n)
+            _, ct, nt = oracle.ccs_masks(co, n)
+            t.set_case_control(cs, ct, nc, nt)
+            counts, stats = t.scan_case_control()
+            wc, ws = oracle.scan_stream_cc(ts, gs, cs, ct, nc, nt)
+            assert np.array_equal(counts, wc), label
+            _assert_stats(stats, ws)
+            g_cs, g_ct, g_nc, g_nt = t.get_case_control()
+            assert np.array_equal(g_cs, cs) and np.array_equal(g_ct, ct) and (g_nc, g_nt) == (nc, nt)
+        # setAllAsCases-style mask with the pad bits set too (case_control_set.cpp:152-169)
+        cs = np.full(gs.data_blocks, 0xFFFF, np.uint16)
+        ct = np.zeros(gs.data_blocks, np.uint16)
+        t.set_case_control(cs, ct, n, 0)
+        counts, _ = t.scan_case_control()
+        assert np.array_equal(counts[:, :4], t.scan_distribution())
+
+
+def test_monomorphic_and_all_missing_rows(oracle):
+    n = 777
+    codes = np.zeros((4, n), np.uint8)
+    codes[1] = 1
+    codes[2] = 2
+    codes[3] = 3
+    ts = oracle.pack_codes(codes, "stream")
+    rng = np.random.default_rng(4)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    with gw.GwTable(n, 4) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        counts, stats = t.scan_case_control()
+        wc, ws = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs, ct, nc, nt)
+        assert np.array_equal(counts, wc)
+        _assert_stats(stats, ws)
+        assert tuple(counts[0]) == (0, 0, 0, nc, 0, 0, 0, nt)
+
+
+def test_argument_errors():
+    with gw.GwTable(100, 10) as t:
+        with pytest.raises(gw.GwError) as e:
+            t.scan_distribution(5, 6)
+        assert e.value.code == -5
+        with pytest.raises(gw.GwError) as e:
+            t.upload_rows(9, np.zeros((2, 2 * gw.stream_blocks(100) + 1), np.uint16))
+        assert e.value.code == -5
+        with pytest.raises(gw.GwError) as e:
+            t.set_case_control(np.zeros(3, np.uint16), np.zeros(3, np.uint16), 0, 0)
+        assert e.value.code == -1
+        with pytest.raises(gw.GwError) as e:
+            t.add_genotype_row(0, b"AC\tCA\t")
+        assert e.value.code == -6
+        assert t.scan_distribution(10, 0).shape == (0, 4)
+    with gw.GwTable(100, 0) as t:   # empty table
+        assert t.scan_distribution().shape == (0, 4)
+
+
+# --------------------------------------------------------------------------
+# pairwise contingency (callers of the scan)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [70, 128, 1000, 4097])
+def test_pair_contingency(oracle, n):
+    m = 12
+    rng = np.random.default_rng(n)
+    codes = _random_codes(rng, m, n, p_missing=0.05)
+    ts = oracle.pack_codes(codes, "stream")
+    gs = oracle.geometry_stream(n)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    pairs = np.array([(i, j) for i in range(m) for j in range(i + 1, m)], dtype=np.uint32)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        got = t.pair_contingency(pairs)
+        t.set_case_control(cs, ct, nc, nt)
+        got_c, got_t = t.pair_case_control_contingency(pairs)
+        for k, (i, j) in enumerate(pairs):
+            assert np.array_equal(got[k], oracle.stream_contingency(ts[i], ts[j], gs))
+            wc, wt = oracle.stream_cc_contingency(ts[i], ts[j], gs, cs, ct)
+            assert np.array_equal(got_c[k], wc) and np.array_equal(got_t[k], wt)
+        with pytest.raises(gw.GwError):
+            t.pair_contingency(np.array([[0, m]], np.uint32))
+
+
+# --------------------------------------------------------------------------
+# the synthetic-input generator: device == oracle restatement
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("n,missing", [(1, 0), (64, 0), (1000, 0), (10_000, 655), (33_333, 0)])
+def test_simulator_equals_oracle(oracle, n, missing):
+    seed, m, first = 0x5EED, 37, 1_000_003
+    with gw.GwTable(n, m) as t:
+        t.simulate(seed, first, missing)
+        t.simulate_phenotype(seed)
+        rows = t.download_rows(0, m)
+        want, g = oracle.sim_table_stream(seed, first, m, n, missing)
+        assert np.array_equal(rows, want)
+        cs, ct, nc, nt = t.get_case_control()
+        ocs, oct_, onc, ont = oracle.sim_phenotype_stream(seed, n)
+        assert np.array_equal(cs, ocs) and np.array_equal(ct, oct_) and (nc, nt) == (onc, ont)
+        counts, stats = t.scan_case_control()
+        wc, ws = oracle.scan_stream_cc(want, g, ocs, oct_, onc, ont)
+        assert np.array_equal(counts, wc)
+        _assert_stats(stats, ws)
