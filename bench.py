@@ -95,7 +95,12 @@ def cpu_baseline(table, n_samples, seconds):
     gpu_counts, gpu_stats = table.scan_case_control(0, sample)
     parity = bool(np.array_equal(gpu_counts, counts)) and bool(
         np.allclose(gpu_stats, stats, rtol=1e-10, atol=1e-12))
-    threads = os.cpu_count() or 1
+    # the GPU box gives a one-GPU job a 16-core share of its host (os.cpu_count() shows all of it)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 16))
     t1 = time.perf_counter()
     mt_passes = 0
     while mt_passes < 2 or time.perf_counter() - t1 < 2.0:
