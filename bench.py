@@ -161,8 +161,9 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     # result buffers (torch = device memory + streams + RCCL plumbing)
-    n_chunks = max(1, min(args.chunks if world > 1 else 1, n_snps))
-    bounds = [(n_snps * c) // n_chunks for c in range(n_chunks + 1)]
+    from libgwaspp_amd import shard
+    bounds = shard.chunk_bounds(n_snps, args.chunks if world > 1 else 1)
+    n_chunks = len(bounds) - 1
     bufs, gathers = [], []
     for c in range(n_chunks):
         rows = bounds[c + 1] - bounds[c]
@@ -180,7 +181,9 @@ def main():
             base = bufs[c].data_ptr()
             table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
             if world > 1:
-                works.append(dist.gather(bufs[c], gathers[c] if rank == 0 else None, dst=0, async_op=True))
+                _, w = shard.gather_records(dist, bufs[c], rank, world, dst=0, async_op=True,
+                                            out=gathers[c] if rank == 0 else None)
+                works.append(w)
         for w in works:
             w.wait()
 

@@ -223,6 +223,11 @@ int gw_get_option(gw_table *t, int option, int64_t *value);
  * (row must hold the layout's blocks-per-row uint16, header first). */
 int gw_pack_genotype_row(const char *begin, const char *end, char delim, uint32_t n_samples,
                          int layout, uint16_t *row);
+/* One step of the row labeller for GenoTable::addGenotype(r, c, gt)
+ * (table5.cpp:156-194): *header is the row's current header block, encoding =
+ * 4*a1+a2 over "ACGT"; *code gets the 2-bit code and *header is updated when
+ * the genotype is new to the row.  GW_E_FORMAT where the reference asserts. */
+int gw_header_assign(uint16_t *header, uint32_t encoding, int *code);
 /* CaseControlSet::setCases / setControls (case_control_set.cpp:77-150) in the
  * stream packing: idx[n_idx] column indices -> mask of gw_stream_blocks(n)
  * uint16; *count = members (duplicates once). */

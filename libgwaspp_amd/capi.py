@@ -66,7 +66,7 @@ EXPORTS = [
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_pair_contingency", "gw_pair_case_control_contingency",
     "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_set_option",
-    "gw_get_option", "gw_pack_genotype_row", "gw_build_stream_mask", "gw_stream_blocks",
+    "gw_get_option", "gw_pack_genotype_row", "gw_header_assign", "gw_build_stream_mask", "gw_stream_blocks",
     "gw_block_blocks",
 ]
 
@@ -109,6 +109,7 @@ def library() -> C.CDLL:
     L.gw_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.gw_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.gw_pack_genotype_row.argtypes = [vp, vp, C.c_char, C.c_uint32, C.c_int, u16p]
+    L.gw_header_assign.argtypes = [u16p, C.c_uint32, C.POINTER(C.c_int)]
     L.gw_build_stream_mask.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, u16p, u32p]
     L.gw_stream_blocks.argtypes = [C.c_uint32]
     L.gw_stream_blocks.restype = C.c_uint32

@@ -383,6 +383,14 @@ int gw_pack_genotype_row(const char *begin, const char *end, char delim, uint32_
     return GW_OK;
 }
 
+int gw_header_assign(uint16_t *header, uint32_t encoding, int *code) {
+    if (!header || !code || encoding > 15u) return fail(GW_E_INVALID, "bad argument");
+    const int c = gw::label_from_header(*header, encoding);
+    if (c == 0) return fail(GW_E_FORMAT, "genotype the reference asserts on for this row");
+    *code = c;
+    return GW_OK;
+}
+
 int gw_build_stream_mask(const int32_t *idx, size_t n_idx, uint32_t n_samples, uint16_t *mask,
                          uint32_t *count) {
     if ((!idx && n_idx) || !mask || n_samples == 0) return fail(GW_E_INVALID, "NULL argument");

@@ -62,6 +62,23 @@ int RowLabeller::code_for(unsigned enc) {
     return m.code;
 }
 
+int label_from_header(uint16_t &header, unsigned enc) {
+    const uint16_t order = header & 0xF000;
+    int stage = 0;
+    for (int i = 0; i < 6; ++i)
+        if (kOrderBits[i] == order) stage = i;
+    const unsigned aa = (header >> 8) & 0xFu, ab = (header >> 4) & 0xFu, bb = header & 0xFu;
+    const bool has_aa = stage == 1 || stage >= 3, has_ab = stage == 2 || stage >= 4, has_bb = stage == 3 || stage == 5;
+    if (has_aa && enc == aa) return 1;
+    if (has_ab && enc == ab) return 2;
+    if (has_bb && enc == bb) return 3;
+    const bool hom = (enc >> 2) == (enc & 3u);
+    const Move &m = kMoves[stage][hom ? 1 : 0];
+    if (m.next < 0) return 0;
+    header = (uint16_t)((header & m.keep) | kOrderBits[m.next] | (uint16_t)(enc << m.shift));
+    return m.code;
+}
+
 int pack_genotype_row(const char *begin, const char *end, uint32_t n_samples, bool block_layout,
                       uint16_t *row) {
     const uint32_t row_blocks = block_layout ? block_row_blocks(n_samples) : stream_row_blocks(n_samples);

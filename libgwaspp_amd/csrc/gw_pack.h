@@ -33,6 +33,11 @@ private:
     uint16_t header_;
 };
 
+// Single-call form of the labeller for GenoTable::addGenotype(r, c, gt)
+// (table5.cpp:156-194): continues from the state recorded in `header`, returns
+// the 2-bit code of `encoding` (0 = the reference asserts) and updates header.
+int label_from_header(uint16_t &header, unsigned encoding);
+
 // text "AC<d>AA<d>..." (two allele symbols + one delimiter per sample; what
 // TpedGenotypeFile hands over, individual/tped_genotype_file.cpp:127-190) ->
 // one row in the chosen reference packing, header block first.

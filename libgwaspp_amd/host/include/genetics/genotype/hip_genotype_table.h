@@ -1,0 +1,104 @@
+// genetics/genotype/hip_genotype_table.h -- the MI355X-backed GenoTable.
+//
+// A new subclass of the reference's abstract table (genotype/geno_table.h:47-87)
+// next to CompressedGenotypeTable3/4/5: the packed genotypes live in HBM (one
+// gw_table handle of include/gwas_scan.h), the per-row getters of
+// SingleMarkerAnalyzable are served from BATCHED device scans.  The callers in
+// algorithms/maf_func.cpp only ever walk r = 0..M-1 in order
+// (maf_func.cpp:304-314), so the first getter call of a window scans the whole
+// window on the GPU and the following calls read the host-side result cache.
+//
+// Semantics kept from CompressedGenotypeTable5 (the 2-bit stream table), incl.
+// its per-method xx conventions:
+//   getGenotypeDistribution            xx = missing + pad bits   (table5.cpp:600)
+//   getCaseControlGenotypeDistribution xx = group - aa - ab - bb (table5.cpp:649,653)
+//   getContingencyTable / cc (inline)  xx_xx absorbs non-members and pad bits (table5.cpp:856)
+//   cc (selected)                      pad bits of the compacted rows (table5.cpp:896-987)
+//   cc (margin-assisted)               exact tables (table5.cpp:989-1150)
+// Errors abort, like the reference's asserts.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "genetics/genotype/geno_table.h"
+
+struct gw_table;  // include/gwas_scan.h
+
+namespace libgwaspp {
+namespace genetics {
+
+class HipGenotypeTable : public GenoTable {
+public:
+    HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device = 0);
+    virtual ~HipGenotypeTable();
+
+    // ---- ingest (geno_table.h:51-53)
+    void addGenotype(int rIdx, int cIdx, const std::string &gt);
+    void addGenotypeRow(int rIdx, std::string::const_iterator &it, std::string::const_iterator &it_end, char delim);
+    void addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim);
+
+    ushort encodeGenotype(const std::string &gt);
+    const char *decodeGenotype(ushort encoded_gt);
+    bool isGenotypeHomozygous(ushort encoded_gt);
+    DataBlock operator()(int r, int c);
+
+    // ---- single marker (single_marker_analyzable.h:132-145)
+    void selectMarker(uint rIdx);
+    void getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist);
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs, CaseControlGenotypeDistribution &ccgd);
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd);
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd, marginal_information &m);
+
+    // ---- pairs (pairwise_marker_analyzable.h:175-187)
+    void selectMarkerPair(uint rIdx1, uint rIdx2);
+    void getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct);
+    void getContingencyTable(uint rIdx1, uint rIdx2, ushort *column_set, ContingencyTable &ct);
+    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs, CaseControlContingencyTable &ccct);
+    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlContingencyTable &ccct);
+    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, const marginal_information &m1,
+                                        const marginal_information &m2, CaseControlContingencyTable &ccct);
+
+    // ---- mask (case_control_selectable.h:42)
+    void selectCaseControl(CaseControlSet &ccs);
+
+    // ---- batch extensions (what the per-row getters are served from)
+    // association statistics of row r computed in the same kernel pass
+    // (include/gwas_scan.h gw_scan_case_control: MAF x3, HWE x2, chi-square x2, call rate)
+    const double *getAssociationStatistics(uint rIdx);
+    // many pairs in one launch; out = n x 16 (and n x 16 for controls)
+    void getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
+                                         std::vector<uint> &cases, std::vector<uint> &ctrls);
+    void setScanWindow(uint rows) { window = rows ? rows : 1; invalidate(); }
+    gw_table *handle() { return tbl; }
+
+protected:
+    void initialize();
+    void invalidate();
+    void install(CaseControlSet &ccs);
+    void fill_dist_cache(uint rIdx);
+    void fill_cc_cache(uint rIdx);
+    void pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABLE_T &ct);
+
+    gw_table *tbl;
+    int device_id;
+    uint n_individs, ref_words;
+    uint window;
+
+    // result caches (host)
+    std::vector<uint> dist_cache, cc_cache;
+    std::vector<double> stat_cache;
+    ulong dist_begin, dist_count, cc_begin, cc_count;
+
+    // installed masks
+    const CaseControlSet *installed;
+    unsigned long installed_rev;
+
+    // operator()(r,c): one decoded row
+    std::vector<ushort> row_cache;
+    long row_cached;
+
+    char gt_text[17][3];
+};
+
+}  // namespace genetics
+}  // namespace libgwaspp

@@ -1,0 +1,289 @@
+// hip_genotype_table.cpp -- see genetics/genotype/hip_genotype_table.h.
+#include "genetics/genotype/hip_genotype_table.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gwas_scan.h"
+
+namespace libgwaspp {
+namespace genetics {
+
+namespace {
+
+// the reference aborts through assert() (kept on at -O3, CMakeLists.txt:34);
+// a failed C-ABI call is the same class of error
+void die_unless_ok(int rc, const char *what) {
+    if (rc != GW_OK) {
+        std::fprintf(stderr, "HipGenotypeTable: %s failed: %s\n", what, gw_last_error());
+        std::abort();
+    }
+}
+void unsupported(const char *what) {
+    // e.g. table5.cpp:434-441, 802-804: assert(false) in the reference too
+    std::fprintf(stderr, "HipGenotypeTable: %s is not implemented (assert(false) in CompressedGenotypeTable5)\n", what);
+    std::abort();
+}
+
+const char kAlphabet[] = GENOTYPE_ALPHABET;
+
+inline void to_freq(const uint *c, frequency_table &ft) {
+    ft.aa = c[0]; ft.ab = c[1]; ft.bb = c[2]; ft.xx = c[3];
+}
+
+}  // namespace
+
+HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
+    : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
+      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), installed(nullptr),
+      installed_rev(0), row_cached(-1) {
+    initialize();
+}
+
+void HipGenotypeTable::initialize() {
+    n_individs = (uint)max_column;
+    die_unless_ok(gw_table_create(device_id, n_individs, (uint64_t)max_row, &tbl), "gw_table_create");
+    ref_words = gw_stream_blocks(n_individs) / BLOCKS_PER_PWORD;
+    // genotype vocabulary: 16 allele pairs + "unknown" (table5.cpp:37, 104-118)
+    possible_genotypes_size = 17;
+    beg = new ushort[possible_genotypes_size];
+    end = beg + possible_genotypes_size;
+    for (uint e = 0; e < 16; ++e) {
+        beg[e] = (ushort)e;
+        gt_text[e][0] = kAlphabet[e >> 2];
+        gt_text[e][1] = kAlphabet[e & 3];
+        gt_text[e][2] = '\0';
+    }
+    beg[16] = 0xFFFF;
+    std::strcpy(gt_text[16], "00");  // err_lookup, table5.cpp:147-149
+    std::cout << "Initializing HipGenotypeTable ... " << max_row << " markers x " << max_column
+              << " individuals resident in HBM" << std::endl;
+}
+
+HipGenotypeTable::~HipGenotypeTable() { gw_table_destroy(tbl); }
+
+void HipGenotypeTable::invalidate() {
+    dist_count = cc_count = 0;
+    row_cached = -1;
+}
+
+// --------------------------------------------------------------------- ingest
+
+void HipGenotypeTable::addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim) {
+    die_unless_ok(gw_table_add_genotype_row(tbl, (uint64_t)rIdx, p_begin, p_end, delim), "addGenotypeRow");
+    invalidate();
+}
+
+void HipGenotypeTable::addGenotypeRow(int rIdx, std::string::const_iterator &it, std::string::const_iterator &it_end,
+                                      char delim) {
+    if (it >= it_end) return;
+    const char *b = &*it;
+    addGenotypeRow(rIdx, b, b + (it_end - it), delim);
+    it = it_end;
+}
+
+void HipGenotypeTable::addGenotype(int rIdx, int cIdx, const std::string &gt) {
+    // read-modify-write of one row in the reference's stream packing
+    gw_geometry g;
+    die_unless_ok(gw_table_geometry(tbl, &g), "gw_table_geometry");
+    std::vector<ushort> row(g.stream_row_bytes / 2);
+    die_unless_ok(gw_table_download_rows(tbl, rIdx, 1, row.data(), g.stream_row_bytes, GW_LAYOUT_STREAM), "download");
+    const ushort enc = encodeGenotype(gt);
+    int code = 0;
+    if (enc != 0xFFFF) die_unless_ok(gw_header_assign(&row[0], enc, &code), "addGenotype (row labelling)");
+    const ushort bit = (ushort)(1u << (cIdx & 15));
+    ushort &lo = row[1 + (cIdx >> 4)], &hi = row[1 + g.stream_blocks + (cIdx >> 4)];
+    lo = (ushort)((lo & ~bit) | ((code & 1) ? bit : 0));
+    hi = (ushort)((hi & ~bit) | ((code & 2) ? bit : 0));
+    die_unless_ok(gw_table_upload_rows(tbl, rIdx, 1, row.data(), g.stream_row_bytes, GW_LAYOUT_STREAM), "upload");
+    invalidate();
+}
+
+ushort HipGenotypeTable::encodeGenotype(const std::string &gt) {
+    if (gt.length() != MAX_ALLELE_COUNT) std::abort();  // assert in table5.cpp:369
+    int v[2];
+    for (int i = 0; i < 2; ++i) {
+        const char *p = std::strchr(kAlphabet, gt[i]);
+        if (!p || !gt[i]) return 0xFFFF;
+        v[i] = (int)(p - kAlphabet);
+    }
+    return (ushort)(4 * v[0] + v[1]);
+}
+
+const char *HipGenotypeTable::decodeGenotype(ushort enc) { return gt_text[enc < 16 ? enc : 16]; }
+
+bool HipGenotypeTable::isGenotypeHomozygous(ushort enc) { return enc < 16 && (enc >> 2) == (enc & 3); }
+
+DataBlock HipGenotypeTable::operator()(int r, int c) {
+    gw_geometry g;
+    die_unless_ok(gw_table_geometry(tbl, &g), "gw_table_geometry");
+    if (row_cached != r) {
+        row_cache.resize(g.stream_row_bytes / 2);
+        die_unless_ok(gw_table_download_rows(tbl, r, 1, row_cache.data(), g.stream_row_bytes, GW_LAYOUT_STREAM),
+                      "download");
+        row_cached = r;
+    }
+    const ushort bit = (ushort)(1u << (c & 15));
+    const bool lo = row_cache[1 + (c >> 4)] & bit, hi = row_cache[1 + g.stream_blocks + (c >> 4)] & bit;
+    const ushort head = row_cache[0];
+    if (lo) return hi ? (head & 0x000F) : ((head >> 8) & 0x000F);  // BB : AA (table5.cpp:399-406)
+    return hi ? ((head >> 4) & 0x000F) : 0xFFFF;                    // AB : unknown
+}
+
+// ------------------------------------------------------------- single marker
+
+void HipGenotypeTable::selectMarker(uint) { unsupported("selectMarker"); }
+void HipGenotypeTable::selectMarkerPair(uint, uint) { unsupported("selectMarkerPair"); }
+void HipGenotypeTable::getContingencyTable(uint, uint, ushort *, ContingencyTable &) {
+    unsupported("getContingencyTable(column_set)");
+}
+
+void HipGenotypeTable::fill_dist_cache(uint rIdx) {
+    const ulong begin = (rIdx / window) * (ulong)window;
+    const ulong n = std::min<ulong>(window, (ulong)max_row - begin);
+    dist_cache.resize(n * 4);
+    die_unless_ok(gw_scan_distribution(tbl, begin, n, dist_cache.data()), "gw_scan_distribution");
+    dist_begin = begin;
+    dist_count = n;
+}
+
+void HipGenotypeTable::getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist) {
+    if (rIdx < dist_begin || rIdx >= dist_begin + dist_count) fill_dist_cache(rIdx);
+    frequency_table ft;
+    to_freq(&dist_cache[(rIdx - dist_begin) * 4], ft);
+    // the stream table counts its pad bits as xx here (table5.cpp:600, quirk Q3)
+    ft.xx += ref_words * 64u - n_individs;
+    dist.setDistribution(ft);
+}
+
+void HipGenotypeTable::install(CaseControlSet &ccs) {
+    if (installed == &ccs && installed_rev == ccs.revision()) return;
+    die_unless_ok(gw_table_set_case_control(tbl, ccs.stream_case_begin(), ccs.stream_control_begin(),
+                                            ccs.stream_block_count(), ccs.getCaseCount(), ccs.getControlCount()),
+                  "gw_table_set_case_control");
+    installed = &ccs;
+    installed_rev = ccs.revision();
+    nCaseCount = ccs.getCaseCount();
+    nControlCount = ccs.getControlCount();
+    nIndivids = nCaseCount + nControlCount;
+    cc_count = 0;
+}
+
+void HipGenotypeTable::selectCaseControl(CaseControlSet &ccs) {
+    // the reference compacts cases and controls into dense planes here
+    // (table5.cpp:443-575, 6.7 s for 10k x 50k); on the GPU the masks are applied
+    // inline at full bandwidth, so "select" only installs them
+    install(ccs);
+}
+
+void HipGenotypeTable::fill_cc_cache(uint rIdx) {
+    if (!installed) {
+        std::fprintf(stderr, "HipGenotypeTable: no CaseControlSet selected\n");
+        std::abort();
+    }
+    const ulong begin = (rIdx / window) * (ulong)window;
+    const ulong n = std::min<ulong>(window, (ulong)max_row - begin);
+    cc_cache.resize(n * GW_N_COUNTS);
+    stat_cache.resize(n * GW_N_STATS);
+    die_unless_ok(gw_scan_case_control(tbl, begin, n, cc_cache.data(), stat_cache.data()), "gw_scan_case_control");
+    cc_begin = begin;
+    cc_count = n;
+}
+
+void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd) {
+    if (rIdx < cc_begin || rIdx >= cc_begin + cc_count) fill_cc_cache(rIdx);
+    frequency_table ca, co;
+    const uint *c = &cc_cache[(rIdx - cc_begin) * GW_N_COUNTS];
+    to_freq(c, ca);
+    to_freq(c + 4, co);
+    ccgd.setCaseDistribution(ca);
+    ccgd.setControlDistribution(co);
+}
+
+void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs,
+                                                          CaseControlGenotypeDistribution &ccgd) {
+    install(ccs);
+    getCaseControlGenotypeDistribution(rIdx, ccgd);
+}
+
+void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd,
+                                                          marginal_information &m) {
+    getCaseControlGenotypeDistribution(rIdx, ccgd);
+    computeMarginalInformation(*ccgd.getCaseDistribution(), *ccgd.getControlDistribution(), nIndivids, m);
+}
+
+const double *HipGenotypeTable::getAssociationStatistics(uint rIdx) {
+    if (rIdx < cc_begin || rIdx >= cc_begin + cc_count) fill_cc_cache(rIdx);
+    return &stat_cache[(rIdx - cc_begin) * GW_N_STATS];
+}
+
+// ----------------------------------------------------------------------- pairs
+
+void HipGenotypeTable::getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct) {
+    const uint pair[2] = {rIdx1, rIdx2};
+    CONTIN_TABLE_T c;
+    die_unless_ok(gw_pair_contingency(tbl, pair, 1, c.contin), "gw_pair_contingency");
+    ct.setMarkerAIndex(rIdx1);
+    ct.setMarkerBIndex(rIdx2);
+    ct.setContingency(c);
+}
+
+void HipGenotypeTable::pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABLE_T &ct) {
+    const uint pair[2] = {r1, r2};
+    die_unless_ok(gw_pair_case_control_contingency(tbl, pair, 1, cs.contin, ct.contin),
+                  "gw_pair_case_control_contingency");
+}
+
+void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs,
+                                                      CaseControlContingencyTable &ccct) {
+    install(ccs);
+    CONTIN_TABLE_T cs, ct;
+    pair_cc(rIdx1, rIdx2, cs, ct);  // masks before decoding: table5.cpp:823-829
+    ccct.setMarkerAIndex(rIdx1);
+    ccct.setMarkerBIndex(rIdx2);
+    ccct.updateContingencyTables(cs, ct);
+}
+
+void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlContingencyTable &ccct) {
+    if (!installed) std::abort();
+    CONTIN_TABLE_T cs, ct;
+    pair_cc(rIdx1, rIdx2, cs, ct);
+    // the reference works on compacted rows here (table5.cpp:896-987): only the
+    // group's members plus the pad bits of the compacted planes reach xx_xx
+    const uint case_words = (((nCaseCount / 16u + 1u) + 3u) & ~3u) / 4u;
+    const uint ctrl_words = (((nControlCount / 16u + 1u) + 3u) & ~3u) / 4u;
+    cs.xx_xx = cs.xx_xx - ref_words * 64u + case_words * 64u;
+    ct.xx_xx = ct.xx_xx - ref_words * 64u + ctrl_words * 64u;
+    ccct.setMarkerAIndex(rIdx1);
+    ccct.setMarkerBIndex(rIdx2);
+    ccct.updateContingencyTables(cs, ct);
+}
+
+void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, const marginal_information &m1,
+                                                      const marginal_information &m2,
+                                                      CaseControlContingencyTable &ccct) {
+    (void)m1; (void)m2;  // the margins only save popcounts on the CPU (table5.cpp:1066-1143)
+    if (!installed) std::abort();
+    CONTIN_TABLE_T cs, ct;
+    pair_cc(rIdx1, rIdx2, cs, ct);
+    // exact tables: xx_xx = members missing at both markers (table5.cpp:1031,1062)
+    cs.xx_xx -= ref_words * 64u - nCaseCount;
+    ct.xx_xx -= ref_words * 64u - nControlCount;
+    ccct.setMarkerAIndex(rIdx1);
+    ccct.setMarkerBIndex(rIdx2);
+    ccct.updateContingencyTables(cs, ct);
+}
+
+void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
+                                                       std::vector<uint> &cases, std::vector<uint> &ctrls) {
+    install(ccs);
+    cases.resize(n_pairs * 16);
+    ctrls.resize(n_pairs * 16);
+    die_unless_ok(gw_pair_case_control_contingency(tbl, pairs, n_pairs, cases.data(), ctrls.data()),
+                  "gw_pair_case_control_contingency");
+}
+
+}  // namespace genetics
+}  // namespace libgwaspp

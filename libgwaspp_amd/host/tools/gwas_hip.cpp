@@ -1,0 +1,132 @@
+// gwas_hip.cpp -- command-line harness over the HipGenotypeTable, after the
+// reference's src/test/gwas_basic.cpp (flags :246-334, dispatch :195-237):
+// reads a transposed-PLINK pair, builds the table through the same
+// GeneticData / GenoTable calls, runs one of the reference's scan harnesses.
+//
+//   gwas_hip -g x.tped -p x.tfam [-o out] MODE
+//   --test-inline-maf      "xx aa ab bb" per SNP (inline_maf_print; the format of
+//                          genotype_set_builder.pl's *.expected.dist)
+//   --test-inline-cc-maf   same for cases and controls -> <out>.case / <out>.control
+//   --inline-cc-maf / --select-cc-maf / --dist-perform    timing harnesses
+//   --valid-geno           every call decoded back (validate_func.cpp:31-55)
+//   --contin-debug         4x4 table of every SNP pair (epistasis_func.cpp:84-103)
+//   --epi-debug            case/control tables of every pair, all three getters
+//   --assoc                counts + MAF/HWE/chi-square of every SNP
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <string>
+
+#include "algorithms/maf_func.h"
+#include "genetics/genotype/hip_genotype_table.h"
+#include "genetics/individual/tplink_files.h"
+
+using namespace libgwaspp::genetics;
+using namespace libgwaspp::algorithms;
+
+static void usage() {
+    std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] "
+                 "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
+                 "--valid-geno|--contin-debug|--epi-debug|--assoc\n";
+    std::exit(2);
+}
+
+static void print_table(std::ostream &o, const CONTIN_TABLE_T &t) {
+    for (int i = 0; i < 16; ++i) o << t.contin[i] << (i == 15 ? "\n" : "\t");
+}
+
+int main(int argc, char **argv) {
+    std::string tped, tfam, out_path, mode;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if ((a == "-g" || a == "--genotype") && i + 1 < argc) tped = argv[++i];
+        else if ((a == "-p" || a == "--phenotype") && i + 1 < argc) tfam = argv[++i];
+        else if ((a == "-o" || a == "--output") && i + 1 < argc) out_path = argv[++i];
+        else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "-t") {}  // transposed input is the only form here
+        else if (a.rfind("--", 0) == 0) mode = a;
+        else usage();
+    }
+    if (tped.empty() || tfam.empty() || mode.empty()) usage();
+
+    GeneticData gd(eHip2BitStream, device);
+    if (!readTfamIndividuals(tfam, &gd) || !readTpedGenotypes(tped, &gd) || !readTfamCaseControl(tfam, &gd)) {
+        std::cerr << "cannot read " << tped << " / " << tfam << std::endl;
+        return 1;
+    }
+    std::ofstream file;
+    std::ostream *out = &std::cout;
+    if (!out_path.empty() && mode != "--test-inline-cc-maf") {
+        file.open(out_path.c_str());
+        out = &file;
+    }
+    GenoTable &gt = *gd.getGenotypeTable();
+    const int M = gd.getGenotypedMarkersCount(), N = gd.getGenotypedIndividualsCount();
+
+    if (mode == "--test-inline-maf") {
+        inline_maf_print(&gd, out);
+    } else if (mode == "--test-inline-cc-maf") {
+        if (out_path.empty()) usage();
+        std::ofstream fc((out_path + ".case").c_str()), ft((out_path + ".control").c_str());
+        inline_cc_maf_print(&gd, &fc, &ft);
+    } else if (mode == "--inline-cc-maf") {
+        inline_cc_maf(&gd, out);
+    } else if (mode == "--select-cc-maf") {
+        select_cc_maf(&gd, out);
+    } else if (mode == "--dist-perform") {
+        genotype_dist_performance(&gd, out);
+    } else if (mode == "--valid-geno") {
+        for (int r = 0; r < M; ++r) {
+            *out << gd.getGenotypedMarkerID(r);
+            for (int c = 0; c < N; ++c) *out << "\t" << gt.getCallAt(r, c);
+            *out << "\n";
+        }
+    } else if (mode == "--contin-debug") {
+        ContingencyTable ct;
+        for (int i = 0; i < M; ++i)
+            for (int j = i + 1; j < M; ++j) {
+                gt.getContingencyTable(i, j, ct);
+                *out << i << "\t" << j << "\t";
+                print_table(*out, *ct.getContingencyTable());
+            }
+    } else if (mode == "--epi-debug") {
+        CaseControlSet &ccs = *gd.getCaseControlSet();
+        CaseControlContingencyTable a, b, c;
+        CaseControlGenotypeDistribution ccgd;
+        gt.selectCaseControl(ccs);
+        std::vector<marginal_information> margins(M);
+        for (int i = 0; i < M; ++i) gt.getCaseControlGenotypeDistribution(i, ccgd, margins[i]);
+        for (int i = 0; i < M; ++i)
+            for (int j = i + 1; j < M; ++j) {
+                gt.getCaseControlContingencyTable(i, j, ccs, a);
+                gt.getCaseControlContingencyTable(i, j, b);
+                gt.getCaseControlContingencyTable(i, j, margins[i], margins[j], c);
+                for (CaseControlContingencyTable *t : {&a, &b, &c}) {
+                    *out << i << "\t" << j << "\tcase\t";
+                    print_table(*out, *t->getCaseContingencyTable());
+                    *out << i << "\t" << j << "\tctrl\t";
+                    print_table(*out, *t->getControlContingencyTable());
+                }
+            }
+    } else if (mode == "--assoc") {
+        HipGenotypeTable &ht = static_cast<HipGenotypeTable &>(gt);
+        CaseControlSet &ccs = *gd.getCaseControlSet();
+        CaseControlGenotypeDistribution ccgd;
+        *out << std::setprecision(17);
+        for (int i = 0; i < M; ++i) {
+            gt.getCaseControlGenotypeDistribution(i, ccs, ccgd);
+            const frequency_table &ca = *ccgd.getCaseDistribution(), &co = *ccgd.getControlDistribution();
+            *out << ca.aa << "\t" << ca.ab << "\t" << ca.bb << "\t" << ca.xx << "\t" << co.aa << "\t" << co.ab
+                 << "\t" << co.bb << "\t" << co.xx;
+            const double *s = ht.getAssociationStatistics(i);
+            for (int k = 0; k < 8; ++k) *out << "\t" << s[k];
+            *out << "\n";
+        }
+    } else {
+        usage();
+    }
+    return 0;
+}

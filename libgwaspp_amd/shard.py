@@ -1,0 +1,50 @@
+"""SNP-range sharding of the scan across ranks and the gather of the per-SNP
+records (plumbing over torch.distributed; RCCL on GPUs, gloo in the CPU tests).
+
+Every SNP row is independent (algorithms/maf_func.cpp:304-314 touches only row
+i and the shared masks), so the path shards by contiguous SNP ranges with no
+data-path collective; the one exchange step is the gather of the 96-byte
+records to rank 0."""
+from __future__ import annotations
+
+
+def snp_range(n_snps_total: int, rank: int, world: int) -> tuple[int, int]:
+    """[begin, end) of the rank's contiguous shard; sizes differ by at most 1."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside the world")
+    base, extra = divmod(n_snps_total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def chunk_bounds(n_rows: int, n_chunks: int) -> list[int]:
+    n_chunks = max(1, min(n_chunks, max(1, n_rows)))
+    return [(n_rows * c) // n_chunks for c in range(n_chunks + 1)]
+
+
+def gather_records(dist, local, rank: int, world: int, dst: int = 0, async_op: bool = False, out=None):
+    """Gathers equally sized 1-D uint8 record buffers to `dst`.  `out` may be a
+    preallocated list of `world` tensors on dst.  Returns (list of per-rank
+    tensors on dst | None, work | None)."""
+    import torch
+    if world == 1:
+        return [local], None
+    if rank != dst:
+        out = None
+    elif out is None:
+        out = [torch.empty_like(local) for _ in range(world)]
+    work = dist.gather(local, out, dst=dst, async_op=async_op)
+    return out, work
+
+
+def gather_ragged(dist, local, rank: int, world: int, sizes: list[int], dst: int = 0):
+    """Shards whose sizes differ (n_snps_total % world != 0): pad to the
+    largest, gather, trim on dst."""
+    import torch
+    biggest = max(sizes)
+    if local.numel() < biggest:
+        local = torch.cat([local, local.new_zeros(biggest - local.numel())])
+    out, _ = gather_records(dist, local, rank, world, dst)
+    if rank != dst:
+        return None
+    return [t[:s] for t, s in zip(out, sizes)]

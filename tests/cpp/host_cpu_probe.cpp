@@ -1,0 +1,76 @@
+// host_cpu_probe.cpp -- exercises the GPU-free parts of the C++ mirror
+// (libgwaspp_amd/host) and prints what they produce, one record per line, for
+// tests/test_host_mirror.py to compare with the oracle and oracle/_ref.
+//   host_cpu_probe ccs <n> <case idx,...> <ctrl idx,...>
+//   host_cpu_probe marginal <8 counts>
+//   host_cpu_probe maf <4 counts>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <sstream>
+#include <string>
+
+#include "algorithms/maf_func.h"
+#include "genetics/analyzable/case_control_set.h"
+#include "genetics/genotype/common_genotype_func.h"
+
+using namespace libgwaspp::genetics;
+
+static std::set<int> parse_set(const char *s) {
+    std::set<int> out;
+    std::stringstream ss(s);
+    std::string tok;
+    while (std::getline(ss, tok, ','))
+        if (!tok.empty() && tok != "-") out.insert(std::atoi(tok.c_str()));
+    return out;
+}
+
+static void dump(const char *name, const ushort *b, const ushort *e) {
+    std::printf("%s", name);
+    for (; b != e; ++b) std::printf(" %04x", (unsigned)*b);
+    std::printf("\n");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    std::string mode = argv[1];
+    if (mode == "ccs" && argc == 5) {
+        util::SequentialIndexer cols(std::atoi(argv[2]));
+        CaseControlSet ccs(&cols);
+        ccs.setCases(parse_set(argv[3]));
+        ccs.setControls(parse_set(argv[4]));
+        dump("block_case", ccs.case_begin(), ccs.case_end());
+        dump("block_ctrl", ccs.control_begin(), ccs.control_end());
+        dump("stream_case", ccs.stream_case_begin(), ccs.stream_case_end());
+        dump("stream_ctrl", ccs.stream_control_begin(), ccs.stream_control_end());
+        std::printf("counts %u %u %u\n", ccs.getCaseCount(), ccs.getControlCount(), ccs.getTotalCount());
+        ccs.setAllAsCases();
+        dump("all_block_case", ccs.case_begin(), ccs.case_end());
+        dump("all_stream_case", ccs.stream_case_begin(), ccs.stream_case_end());
+        return 0;
+    }
+    if (mode == "marginal" && argc == 10) {
+        frequency_table ca, co;
+        for (int i = 0; i < 4; ++i) { ca.freq[i] = std::atoi(argv[2 + i]); co.freq[i] = std::atoi(argv[6 + i]); }
+        uint n = 0;
+        for (int i = 0; i < 4; ++i) n += ca.freq[i] + co.freq[i];
+        marginal_information m;
+        for (int i = 0; i < 8; ++i) m.dPbc[i] = m.dPca[i] = 0.0;
+        computeMarginalInformation(ca, co, n, m);
+        std::printf("%u %u %u %u %.17g %.17g", m.margins.aa, m.margins.ab, m.margins.bb, m.margins.xx,
+                    m.dMarginalEntropy, m.dMarginalEntropy_Y);
+        for (int i = 0; i < 8; ++i) std::printf(" %.17g", m.dPbc[i]);
+        for (int i = 0; i < 8; ++i) std::printf(" %.17g", m.dPca[i]);
+        std::printf("\n");
+        return 0;
+    }
+    if (mode == "maf" && argc == 6) {
+        frequency_table ft;
+        for (int i = 0; i < 4; ++i) ft.freq[i] = std::atoi(argv[2 + i]);
+        double tot, maf;
+        libgwaspp::algorithms::MinorAlleleFrequency(ft, tot, maf);
+        std::printf("%.17g %.17g\n", tot, maf);
+        return 0;
+    }
+    return 2;
+}

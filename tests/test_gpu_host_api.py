@@ -1,0 +1,136 @@
+"""The reference's own test flow against the drop-in table: the CLI harness
+(libgwaspp_amd/bin/gwas_hip, after src/test/gwas_basic.cpp) reads the golden
+.tped/.tfam pairs through GeneticData -> GenoTable::addGenotypeRow and prints
+per-SNP counts, which are diffed with genotype_set_builder.pl's expected files
+(SURVEY.md section 4).  Needs a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import libgwaspp_amd as gw
+from golden_util import (PERL_DIR, expected_in_table_space, golden_sets, read_dist, read_tfam_status,
+                         read_tped)
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "libgwaspp_amd", "bin", "gwas_hip")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _cli():
+    if gw.device_count() == 0:
+        pytest.fail("no HIP device visible")
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "libgwaspp_amd", "host"), "-s"], check=True)
+
+
+def _run(name, mode, out=None):
+    cmd = [CLI, "-g", os.path.join(PERL_DIR, name + ".tped"), "-p", os.path.join(PERL_DIR, name + ".tfam")]
+    if out:
+        cmd += ["-o", out]
+    r = subprocess.run(cmd + [mode], check=True, capture_output=True, text=True)
+    return r.stdout
+
+
+def _table_lines(text):
+    # the table constructors log to stdout like the reference's: keep number rows only
+    rows = []
+    for ln in text.splitlines():
+        t = ln.split()
+        if t and all(x.lstrip("-").isdigit() for x in t):
+            rows.append([int(x) for x in t])
+    return rows
+
+
+@pytest.mark.parametrize("name", golden_sets("plain"))
+def test_inline_maf_print_equals_expected_dist(name):
+    lines = read_tped(name)
+    exp = read_dist(name, "dist")
+    rows = _table_lines(_run(name, "--test-inline-maf"))
+    assert len(rows) == len(lines)
+    for r, ln in enumerate(lines):
+        aa, ab, bb, xx = expected_in_table_space(exp[r], ln)
+        assert rows[r] == [xx, aa, ab, bb]     # "xx aa ab bb", maf_func.cpp:332
+
+
+@pytest.mark.parametrize("name", golden_sets("cc"))
+def test_inline_cc_print_equals_expected_dists(name, tmp_path):
+    lines = read_tped(name)
+    exp_c, exp_t = read_dist(name, "case.dist"), read_dist(name, "control.dist")
+    out = str(tmp_path / "cc")
+    _run(name, "--test-inline-cc-maf", out)
+    got_c = _table_lines(open(out + ".case").read())
+    got_t = _table_lines(open(out + ".control").read())
+    assert len(got_c) == len(got_t) == len(lines)
+    for r, ln in enumerate(lines):
+        aa, ab, bb, xx = expected_in_table_space(exp_c[r], ln)
+        assert got_c[r] == [xx, aa, ab, bb]
+        aa, ab, bb, xx = expected_in_table_space(exp_t[r], ln)
+        assert got_t[r] == [xx, aa, ab, bb]
+
+
+@pytest.mark.parametrize("name", ["plain_m4_n1", "plain_m4_n17", "plain_m4_n129", "plain_m40_n70"])
+def test_valid_geno_round_trip(name):
+    """--valid-geno (validate_func.cpp:31-55): every call decodes back to the text."""
+    lines = read_tped(name)
+    out = [ln.split("\t") for ln in _run(name, "--valid-geno").splitlines() if ln.startswith("rs")]
+    assert len(out) == len(lines)
+    for r, ln in enumerate(lines):
+        t = ln.split()
+        want = [(a + b) if a != "0" else "00" for a, b in zip(t[4::2], t[5::2])]
+        assert out[r][0] == t[1] and out[r][1:] == want
+
+
+@pytest.mark.parametrize("name", ["cc_m6_n70", "cc_m4_n129", "cc_m4_n16"])
+def test_epi_debug_three_getters(oracle, name):
+    """The three getCaseControlContingencyTable overloads, with the xx_xx
+    conventions of table5.cpp:806-895 (inline), :896-987 (compacted) and
+    :989-1150 (margin-assisted)."""
+    n = int(name.split("_n")[1])
+    lines = read_tped(name)
+    cases, ctrls = read_tfam_status(name)
+    ts = oracle.pack_rows([oracle.tped_genotype_text(ln) for ln in lines], n)
+    gs = oracle.geometry_stream(n)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    rows = [ln.split("\t") for ln in _run(name, "--epi-debug").splitlines() if "\tcase\t" in ln or "\tctrl\t" in ln]
+    k = 0
+    m = len(lines)
+    import ctypes as C
+    cb, tb = C.c_uint32(), C.c_uint32()
+    oracle.lib().gwo_compact_geometry(nc, nt, C.byref(cb), C.byref(tb))
+    for i in range(m):
+        for j in range(i + 1, m):
+            wc, wt = oracle.stream_cc_contingency(ts[i], ts[j], gs, cs, ct)
+            for variant in range(3):
+                for which, want, members, words in (("case", wc, nc, cb.value // 4), ("ctrl", wt, nt, tb.value // 4)):
+                    got = rows[k]
+                    k += 1
+                    assert got[:3] == [str(i), str(j), which]
+                    vals = np.array([int(v) for v in got[3:]], dtype=np.int64)
+                    w = want.astype(np.int64).copy()
+                    if variant == 1:      # compacted rows: pad bits of the compacted planes
+                        w[15] += words * 64 - gs.words * 64
+                    elif variant == 2:    # margin-assisted: exact
+                        w[15] -= gs.words * 64 - members
+                    assert np.array_equal(vals, w), (i, j, variant, which)
+    assert k == len(rows)
+
+
+def test_assoc_statistics(oracle):
+    name = "cc_m24_n1000"
+    n = 1000
+    lines = read_tped(name)
+    cases, ctrls = read_tfam_status(name)
+    ts = oracle.pack_rows([oracle.tped_genotype_text(ln) for ln in lines], n)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    wc, ws = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs, ct, nc, nt)
+    rows = [ln.split("\t") for ln in _run(name, "--assoc").splitlines() if ln.count("\t") == 15]
+    assert len(rows) == len(lines)
+    for r, t in enumerate(rows):
+        assert [int(v) for v in t[:8]] == [int(v) for v in wc[r]]
+        np.testing.assert_allclose([float(v) for v in t[8:]], ws[r], rtol=1e-10, atol=1e-12)

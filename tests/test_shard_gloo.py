@@ -1,0 +1,105 @@
+"""The N > 1 path on CPU: SNP-range sharding + the gather of per-SNP records,
+two gloo ranks.  The GPU kernels cannot run here, so each rank's records come
+from the oracle on its shard of the synthetic table (global SNP index =
+shard begin + row, as bench.py generates them); rank 0 checks the gathered
+result against a single-process scan of the whole range."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORD = 96
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _records(oracle, seed, begin, count, n):
+    table, g = oracle.sim_table_stream(seed, begin, count, n)
+    cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+    counts, stats = oracle.scan_stream_cc(table, g, cs, ct, nc, nt)
+    # the layout bench.py hands to RCCL: counts block then stats block
+    return np.concatenate([counts.view(np.uint8).reshape(-1), stats.view(np.uint8).reshape(-1)])
+
+
+def _worker(rank, world, port, total, n, seed, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from libgwaspp_amd import shard
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = []
+        for r in range(world):
+            b, e = shard.snp_range(total, r, world)
+            sizes.append((e - b) * RECORD)
+        begin, end = shard.snp_range(total, rank, world)
+        local = torch.from_numpy(_records(oracle, seed, begin, end - begin, n).copy())
+        got = shard.gather_ragged(dist, local, rank, world, sizes)
+        # the chunked form bench.py uses (equal chunk sizes on every rank)
+        even = (total // world) * world
+        b2, e2 = shard.snp_range(even, rank, world)
+        bounds = shard.chunk_bounds(e2 - b2, 3)
+        chunks = []
+        for c in range(3):
+            rec = torch.from_numpy(_records(oracle, seed, b2 + bounds[c], bounds[c + 1] - bounds[c], n).copy())
+            out, work = shard.gather_records(dist, rec, rank, world, async_op=True)
+            chunks.append((out, work))
+        for _, w in chunks:
+            w.wait()
+        if rank == 0:
+            q.put(([t.numpy() for t in got], [[t.numpy() for t in out] for out, _ in chunks], bounds))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_snp_range_partition():
+    from libgwaspp_amd import shard
+    for total in (0, 1, 7, 8, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            spans = [shard.snp_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.snp_range(10, 2, 2)
+    assert shard.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert shard.chunk_bounds(2, 4) == [0, 1, 2]
+
+
+def test_two_rank_gather_equals_single_process(oracle):
+    import torch.multiprocessing as mp
+    world, total, n, seed = 2, 37, 3000, 0x5EED
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, chunked, bounds = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from libgwaspp_amd import shard
+    for r in range(world):
+        b, e = shard.snp_range(total, r, world)
+        assert np.array_equal(got[r], _records(oracle, seed, b, e - b, n))
+    even = (total // world) * world
+    for c in range(3):
+        for r in range(world):
+            b, _ = shard.snp_range(even, r, world)
+            want = _records(oracle, seed, b + bounds[c], bounds[c + 1] - bounds[c], n)
+            assert np.array_equal(chunked[c][r], want)
