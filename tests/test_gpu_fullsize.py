@@ -50,7 +50,8 @@ def test_full_size_properties(oracle, cfg):
         t.set_case_control(ct, cs, nt, nc)
         swapped, sstats = t.scan_case_control()
         assert np.array_equal(swapped[:, :4], counts[:, 4:]) and np.array_equal(swapped[:, 4:], counts[:, :4])
-        assert np.array_equal(sstats[:, 5:7], stats[:, 5:7])   # the tests are symmetric in the groups
+        # the two association tests are symmetric in the groups (up to summation order)
+        np.testing.assert_allclose(sstats[:, 5:7], stats[:, 5:7], rtol=1e-11, atol=1e-13)
         t.set_case_control(cs, ct, nc, nt)
 
         # differently shaped kernels: masks through L2 instead of LDS, other unroll / geometry
