@@ -208,11 +208,13 @@ int gw_synchronize(gw_table *t);
 
 /* kernel-shape knobs for A/B measurement (defaults are chosen at create) */
 typedef enum gw_option {
-    GW_OPT_UNROLL = 1,       /* 16-byte units per lane in flight per plane: 1,2,4,8 */
+    GW_OPT_UNROLL = 1,       /* 16-byte units per lane in flight per plane: 0 (auto),1,2,4,8 */
     GW_OPT_MASK_IN_LDS = 2,  /* 1: stage masks in LDS (default when they fit); 0: read via L2 */
     GW_OPT_BLOCKS_PER_CU = 3,/* persistent workgroups per CU (0 = auto)          */
     GW_OPT_NONTEMPORAL = 4,  /* 1: nt loads for the genotype stream (default)     */
-    GW_OPT_BLOCK_THREADS = 5 /* threads per workgroup: 256, 512, 1024 (0 = auto) */
+    GW_OPT_BLOCK_THREADS = 5,/* threads per workgroup: 256, 512, 1024 (0 = auto) */
+    GW_OPT_PIPELINE = 6      /* 1: next step's loads issued before the current step is consumed,
+                                across row boundaries; 0: row-at-a-time kernel (default) */
 } gw_option;
 int gw_set_option(gw_table *t, int option, int64_t value);
 int gw_get_option(gw_table *t, int option, int64_t *value);

@@ -1,6 +1,9 @@
 """ctypes view of the C-ABI in include/gwas_scan.h (libgwaspp_amd/libgwscan.so).
 
-Plumbing only: argument marshalling with numpy, no arithmetic.  There is no
+Plumbing only: argument marshalling with numpy, no arithmetic.  A process that
+also uses torch must `import torch` BEFORE the first call here: torch's wheel
+bundles its own libamdhip64 (same SONAME), and whichever HIP runtime is loaded
+first serves both; loading ROCm's first leaves torch without a device.  There is no
 fallback path -- if the shared library is missing or no GPU is present the
 calls raise.
 """
@@ -20,7 +23,7 @@ LAYOUT_BLOCK = 3
 N_COUNTS = 8
 N_STATS = 8
 
-OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS = 1, 2, 3, 4, 5
+OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS, OPT_PIPELINE = 1, 2, 3, 4, 5, 6
 
 
 class GwError(RuntimeError):

@@ -70,7 +70,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 4, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = 0;
 };
 
 namespace {
@@ -83,18 +83,30 @@ int use_device(gw_table *t) {
 hipStream_t pick_stream(gw_table *t, void *s) { return s ? (hipStream_t)s : t->stream; }
 
 gw::ScanShape scan_shape(const gw_table *t) {
+    // Defaults from the round-1 sweeps on MI355X (profiles/r01_sweep_*.txt):
+    //   masks fill more than half the LDS (N > ~320 k): one 512-thread workgroup per CU,
+    //     2 units per lane per plane in flight -- fewer, fatter streams read HBM best;
+    //   masks fit several times: 1024-thread workgroups, 1 unit in flight, up to 4 per CU;
+    //   masks do not fit (N > ~650 k): read through L2, 4 units in flight.
     gw::ScanShape sh{};
-    const size_t need = (size_t)2 * t->tv.units * sizeof(gw::u32x4);
-    const bool fits = need <= t->lds_cap;
-    sh.mask_in_lds = (t->opt_mask_lds < 0) ? (fits ? 1 : 0) : (t->opt_mask_lds && fits ? 1 : 0);
-    sh.lds_bytes = sh.mask_in_lds ? need : 0;
-    sh.unroll = t->opt_unroll;
+    sh.pipeline = t->opt_pipeline;
     sh.nontemporal = t->opt_nt;
-    int threads = t->opt_threads;
-    int per_cu = t->opt_blocks_per_cu;
-    const int lds_limit = sh.mask_in_lds ? (int)(t->lds_cap / need) : 8;
-    if (threads == 0) threads = (sh.mask_in_lds && lds_limit < 2) ? 1024 : 512;
-    if (per_cu == 0) per_cu = std::max(1, std::min(lds_limit, 2048 / threads));
+    const size_t raw_need = (size_t)2 * t->tv.units * sizeof(gw::u32x4);
+    const bool want_lds = (t->opt_mask_lds < 0) ? true : (t->opt_mask_lds != 0);
+    bool lds = want_lds && raw_need <= t->lds_cap;
+    const bool one_per_cu = lds && 2 * raw_need > t->lds_cap;
+    int unroll = t->opt_unroll ? t->opt_unroll : (!lds ? 4 : (one_per_cu ? 2 : 1));
+    // the continuous-stream kernel keeps the masks zero-padded to a whole step in LDS
+    const uint32_t step = 64u * (uint32_t)unroll;
+    const uint32_t lds_units = sh.pipeline ? ((t->tv.units + step - 1u) / step) * step : t->tv.units;
+    const size_t need = (size_t)2 * lds_units * sizeof(gw::u32x4);
+    if (lds && need > t->lds_cap) lds = false;
+    sh.mask_in_lds = lds ? 1 : 0;
+    sh.lds_bytes = lds ? need : 0;
+    sh.unroll = unroll;
+    const int lds_limit = lds ? (int)(t->lds_cap / need) : 8;
+    int threads = t->opt_threads ? t->opt_threads : (one_per_cu ? 512 : 1024);
+    int per_cu = t->opt_blocks_per_cu ? t->opt_blocks_per_cu : (one_per_cu ? 1 : 4);
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
     sh.grid_blocks = t->compute_units * per_cu;
@@ -228,7 +240,8 @@ int gw_table_create(int device, uint32_t n_samples, uint64_t n_snps, gw_table **
         GW_HIP_T(hipMalloc((void **)&t->tv.base, g.device_table_bytes));
         GW_HIP_T(hipMemsetAsync(t->tv.base, 0, g.device_table_bytes, t->stream));
     }
-    const size_t mask_bytes = (size_t)t->tv.plane_stride_u * 16u;
+    // masks are zero-padded to a whole number of the widest scan step (8 x 64 units)
+    const size_t mask_bytes = (size_t)((t->tv.units + 511u) / 512u) * 512u * 16u;
     GW_HIP_T(hipMalloc((void **)&t->d_case, mask_bytes));
     GW_HIP_T(hipMalloc((void **)&t->d_ctrl, mask_bytes));
     GW_HIP_T(hipMemsetAsync(t->d_case, 0, mask_bytes, t->stream));
@@ -614,7 +627,8 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
     if (!t) return fail(GW_E_INVALID, "NULL table");
     switch (option) {
     case GW_OPT_UNROLL:
-        if (v != 1 && v != 2 && v != 4 && v != 8) return fail(GW_E_INVALID, "unroll must be 1, 2, 4 or 8");
+        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8)
+            return fail(GW_E_INVALID, "unroll must be 0 (auto), 1, 2, 4 or 8");
         t->opt_unroll = (int)v;
         return GW_OK;
     case GW_OPT_MASK_IN_LDS:
@@ -633,6 +647,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
             return fail(GW_E_INVALID, "block_threads must be 0 (auto), 256, 512 or 1024");
         t->opt_threads = (int)v;
         return GW_OK;
+    case GW_OPT_PIPELINE:
+        t->opt_pipeline = v ? 1 : 0;
+        return GW_OK;
     default:
         return fail(GW_E_INVALID, "unknown option %d", option);
     }
@@ -647,6 +664,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BLOCKS_PER_CU: *v = t->compute_units ? sh.grid_blocks / t->compute_units : 0; return GW_OK;
     case GW_OPT_NONTEMPORAL: *v = sh.nontemporal; return GW_OK;
     case GW_OPT_BLOCK_THREADS: *v = sh.block_threads; return GW_OK;
+    case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }
 }

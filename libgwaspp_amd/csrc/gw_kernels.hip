@@ -35,6 +35,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Sum over the 64 lanes without touching LDS: four DPP adds fold each 16-lane
+// row (quad swaps, half mirror, full mirror), four v_readlane pick the row
+// sums.  The result is wave-uniform (lives in an SGPR).
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // one 16-byte unit of both planes against both masks: 6 running popcounts
 // (table5.cpp:629-646: aa += pc(p0&m), ab += pc(p1&m), bb += pc(p0&p1&m))
 __device__ __forceinline__ void acc_unit(const u32x4 a, const u32x4 b, const u32x4 mc,
@@ -167,7 +179,7 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
     constexpr uint32_t STEP = 64u * UNROLL;
     const uint32_t full = (units / STEP) * STEP;
@@ -224,10 +236,148 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     }
 }
 
+
+// ---- row epilogue shared by both scan kernels (table5.cpp:647-653 + section 5 of DESIGN.md)
+__device__ __forceinline__ void finish_row(const ScanArgs &a, uint32_t r, const uint32_t (&s)[6]) {
+    uint32_t ca[4], co[4];
+    ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
+    ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
+    co[2] = s[5]; co[0] = s[3] - s[5]; co[1] = s[4] - s[5];
+    co[3] = a.ctrl_count - co[0] - co[1] - co[2];
+    u32x4 *out = reinterpret_cast<u32x4 *>(a.counts + (size_t)r * 8u);
+    u32x4 v0 = {ca[0], ca[1], ca[2], ca[3]};
+    u32x4 v1 = {co[0], co[1], co[2], co[3]};
+    out[0] = v0;
+    out[1] = v1;
+    if (a.stats) {
+        double st[8];
+        assoc_stats(ca, co, st);
+        double *so = a.stats + (size_t)r * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) so[j] = st[j];
+    }
+}
+
+// One step = UNROLL 1-KiB wave-loads per plane.  Never predicated: a lane past
+// the end of the row re-reads the row's last unit (its mask words are zero), so
+// that the compiler can count the loads in flight and wait for exactly the
+// older buffer (a load under a divergent branch forces vmcnt(0)).
+template <int UNROLL, bool NT>
+__device__ __forceinline__ void load_step(const u32x4 *p0, const u32x4 *p1, uint32_t first, uint32_t lane,
+                                          uint32_t last_unit, u32x4 (&A)[UNROLL], u32x4 (&B)[UNROLL]) {
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+        const uint32_t u = min(first + 64u * k + lane, last_unit);
+        A[k] = ld_stream<NT>(p0 + u);
+        B[k] = ld_stream<NT>(p1 + u);
+    }
+}
+
+// Continuous-stream form of the scan: the loads of the NEXT step -- the next
+// step of this row or the first step of the wave's next row -- are issued
+// before the current step is consumed, so the HBM stream never drains across
+// the per-row reduction and FP64 epilogue.  Same ownership (one wave per row),
+// same results.
+template <int UNROLL, bool MASK_LDS, bool NT>
+__global__ void __launch_bounds__(1024) k_scan_cc_pipe(ScanArgs a) {
+    extern __shared__ u32x4 lds_masks[];  // [2][steps * STEP] when MASK_LDS, zero past `units`
+    const uint32_t units = a.units;
+    constexpr uint32_t STEP = 64u * UNROLL;
+    const uint32_t steps = (units + STEP - 1u) / STEP;
+    const uint32_t padded = steps * STEP;  // <= the zero-padded length of the global masks
+    const u32x4 *mcase = a.case_mask;
+    const u32x4 *mctrl = a.ctrl_mask;
+    if (MASK_LDS) {
+        for (uint32_t u = threadIdx.x; u < padded; u += blockDim.x) {
+            lds_masks[u] = a.case_mask[u];
+            lds_masks[padded + u] = a.ctrl_mask[u];
+        }
+        __syncthreads();
+        mcase = lds_masks;
+        mctrl = lds_masks + padded;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    // wave-uniform values kept in SGPRs: row indices and row base addresses are scalar arithmetic
+    const uint32_t waves_per_block = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = __builtin_amdgcn_readfirstlane(gridDim.x * waves_per_block);
+    const uint32_t last_unit = units - 1u;
+
+    // The wave's work is one flat sequence of (row, step) items; two register
+    // buffers ping-pong so that item i+1 is always in flight while item i is
+    // consumed, also across the row boundary (reduction + FP64 epilogue).
+    uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + wave);
+    if (r >= a.n_rows) return;  // no barrier below
+    uint32_t s = 0;
+    u32x4 A0[UNROLL], B0[UNROLL], A1[UNROLL], B1[UNROLL];
+    uint32_t c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+
+    auto consume = [&](const u32x4 (&A)[UNROLL], const u32x4 (&B)[UNROLL], uint32_t row, uint32_t step) {
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const uint32_t u = step * STEP + 64u * k + lane;
+            const u32x4 mc = mcase[u];
+            const u32x4 mt = mctrl[u];
+            if (k & 1) acc_unit(A[k], B[k], mc, mt, c1);
+            else acc_unit(A[k], B[k], mc, mt, c0);
+        }
+        if (step + 1u == steps) {  // wave-uniform: the row is complete
+            uint32_t sum[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                sum[j] = wave_sum_dpp(c0[j] + c1[j]);
+                c0[j] = 0;
+                c1[j] = 0;
+            }
+            if (lane == 0) finish_row(a, row, sum);
+        }
+    };
+
+    {
+        const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
+        load_step<UNROLL, NT>(p0, p0 + a.plane_stride_u, 0, lane, last_unit, A0, B0);
+    }
+    for (;;) {
+        // item after (r, s).  Its loads are issued unconditionally -- past the
+        // wave's last row they re-read the current row (a few KiB per wave per
+        // launch) -- because a conditionally issued load makes the load count
+        // unknown to the compiler, which then waits for vmcnt(0).
+        uint32_t r1 = r, s1 = s + 1u;
+        if (s1 == steps) { r1 = r + total_waves; s1 = 0; }
+        r1 = __builtin_amdgcn_readfirstlane(r1);  // the row walk stays in SGPRs
+        s1 = __builtin_amdgcn_readfirstlane(s1);
+        const bool have1 = r1 < a.n_rows;
+        {
+            const u32x4 *q0 = a.table + (a.row_begin + (have1 ? r1 : r)) * a.row_stride_u;
+            load_step<UNROLL, NT>(q0, q0 + a.plane_stride_u, s1 * STEP, lane, last_unit, A1, B1);
+        }
+        consume(A0, B0, r, s);
+        if (!have1) break;
+        // item after (r1, s1)
+        uint32_t r2 = r1, s2 = s1 + 1u;
+        if (s2 == steps) { r2 = r1 + total_waves; s2 = 0; }
+        r2 = __builtin_amdgcn_readfirstlane(r2);
+        s2 = __builtin_amdgcn_readfirstlane(s2);
+        const bool have2 = r2 < a.n_rows;
+        {
+            const u32x4 *t0 = a.table + (a.row_begin + (have2 ? r2 : r1)) * a.row_stride_u;
+            load_step<UNROLL, NT>(t0, t0 + a.plane_stride_u, s2 * STEP, lane, last_unit, A0, B0);
+        }
+        consume(A1, B1, r1, s1);
+        if (!have2) break;
+        r = r2;
+        s = s2;
+    }
+}
+
 template <int UNROLL, bool MASK_LDS, bool NT>
 static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
-    hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
-                       dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
+    if (sh.pipeline)
+        hipLaunchKernelGGL((k_scan_cc_pipe<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
+                           dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
+    else
+        hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
+                           dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
     return hipGetLastError();
 }
 
@@ -273,7 +423,13 @@ static hipError_t prepare_u(size_t bytes) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<UNROLL, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<UNROLL, true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 

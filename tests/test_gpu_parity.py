@@ -150,14 +150,15 @@ def test_every_kernel_shape_gives_identical_results(oracle, n, m):
         for unroll in (1, 2, 4, 8):
             for lds in (0, 1):
                 for nt_loads in (0, 1):
-                    for threads, per_cu in ((256, 4), (512, 2), (1024, 1), (0, 0)):
+                    for threads, per_cu, pipe in ((256, 4, 1), (512, 2, 0), (1024, 1, 1), (0, 0, 0), (0, 0, 1)):
+                        t.set_option(capi.OPT_PIPELINE, pipe)
                         t.set_option(capi.OPT_UNROLL, unroll)
                         t.set_option(capi.OPT_MASK_IN_LDS, lds)
                         t.set_option(capi.OPT_NONTEMPORAL, nt_loads)
                         t.set_option(capi.OPT_BLOCK_THREADS, threads)
                         t.set_option(capi.OPT_BLOCKS_PER_CU, per_cu)
                         counts, stats = t.scan_case_control()
-                        assert np.array_equal(counts, want_counts), (unroll, lds, nt_loads, threads)
+                        assert np.array_equal(counts, want_counts), (unroll, lds, nt_loads, threads, pipe)
                         _assert_stats(stats, want_stats)
 
 
