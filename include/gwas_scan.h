@@ -194,6 +194,34 @@ int gw_pair_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, ui
 int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs,
                                      uint32_t *out_case, uint32_t *out_ctrl);
 
+/* ---- BOOST / KSA pre-screen over SNP pairs ----
+ * replaces the O(M^2) pre-screening loop of computeBoost
+ * (algorithms/epistasis_func.cpp:349-506): selectCaseControl (table5.cpp:443-575),
+ * computeMargins (:706-721), then for every pair i < j with i in
+ * [a_begin, a_begin+n_a) and j in [b_begin, b_begin+n_b) the margin-assisted
+ * case/control tables (table5.cpp:989-1150) and the interaction measure
+ * (:424-470); pairs whose measure exceeds `threshold` (30.0 in the reference,
+ * :390,482) are listed.  The block form lets callers shard the pair space.
+ * hits[max_hits] receives at most max_hits entries in no particular order;
+ * *n_hits is the total found (may exceed max_hits), *n_pairs the pairs
+ * evaluated, *max_measure / *min_measure the extremes (:472-480). */
+typedef struct gw_boost_hit {
+    uint32_t snp_a, snp_b;
+    double measure;
+} gw_boost_hit;
+int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
+                    double threshold, gw_boost_hit *hits, uint64_t max_hits, uint64_t *n_hits,
+                    uint64_t *n_pairs, double *max_measure, double *min_measure);
+/* every measure of a (small) block, row-major n_a x n_b; NaN where i >= j */
+int gw_boost_measures(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
+                      double *measures);
+/* selectCaseControl's compacted rows (table5.cpp:443-575) as the reference
+ * stores them in m_cases_controls: per row 2*(case_blocks+ctrl_blocks) uint16,
+ * [case plane0 | case plane1 | ctrl plane0 | ctrl plane1], blocks = count/16+1
+ * rounded up to x4 (:449-468).  rows may be NULL to query the block counts. */
+int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint16_t *rows,
+                               uint32_t *case_blocks, uint32_t *ctrl_blocks);
+
 /* ---- measurement ----------------------------------------------------------
  * HIP events on the stream the kernels are launched on (NULL = the handle's
  * stream).  gw_timer_stop synchronises on the stop event and returns the

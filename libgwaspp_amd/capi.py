@@ -68,6 +68,7 @@ EXPORTS = [
     "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_pair_contingency", "gw_pair_case_control_contingency",
+    "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected",
     "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_set_option",
     "gw_get_option", "gw_pack_genotype_row", "gw_header_assign", "gw_build_stream_mask", "gw_stream_blocks",
     "gw_block_blocks",
@@ -105,6 +106,10 @@ def library() -> C.CDLL:
     L.gw_scan_distribution_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp]
     L.gw_pair_contingency.argtypes = [vp, u32p, C.c_uint64, u32p]
     L.gw_pair_case_control_contingency.argtypes = [vp, u32p, C.c_uint64, u32p, u32p]
+    L.gw_boost_screen.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, vp, C.c_uint64,
+                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f64p, f64p]
+    L.gw_boost_measures.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, f64p]
+    L.gw_table_download_selected.argtypes = [vp, C.c_uint64, C.c_uint64, u16p, u32p, u32p]
     L.gw_timer_start.argtypes = [vp, vp]
     L.gw_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.gw_stream_read_probe.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
@@ -284,6 +289,31 @@ class GwTable:
         b = np.zeros((pairs.shape[0], 16), dtype=np.uint32)
         _check(self._L.gw_pair_case_control_contingency(self._h, _p32(pairs), pairs.shape[0], _p32(a), _p32(b)))
         return a, b
+
+    # ---- BOOST / KSA pre-screen
+    def boost_screen(self, a_begin: int, n_a: int, b_begin: int, n_b: int, threshold: float = 30.0,
+                     max_hits: int = 1 << 20):
+        """-> (hits structured array [snp_a, snp_b, measure], n_hits, n_pairs, max, min)"""
+        dt = np.dtype([("snp_a", np.uint32), ("snp_b", np.uint32), ("measure", np.float64)])
+        hits = np.zeros(max_hits, dtype=dt)
+        nh, npairs = C.c_uint64(0), C.c_uint64(0)
+        vmax, vmin = C.c_double(0), C.c_double(0)
+        _check(self._L.gw_boost_screen(self._h, a_begin, n_a, b_begin, n_b, threshold, hits.ctypes.data, max_hits,
+                                       C.byref(nh), C.byref(npairs), C.byref(vmax), C.byref(vmin)))
+        return hits[:min(nh.value, max_hits)], nh.value, npairs.value, vmax.value, vmin.value
+
+    def boost_measures(self, a_begin: int, n_a: int, b_begin: int, n_b: int) -> np.ndarray:
+        out = np.zeros((n_a, n_b), dtype=np.float64)
+        _check(self._L.gw_boost_measures(self._h, a_begin, n_a, b_begin, n_b,
+                                         out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def download_selected(self, snp_begin: int, n_rows: int):
+        cb, tb = C.c_uint32(0), C.c_uint32(0)
+        _check(self._L.gw_table_download_selected(self._h, snp_begin, 0, None, C.byref(cb), C.byref(tb)))
+        rows = np.zeros((n_rows, 2 * (cb.value + tb.value)), dtype=np.uint16)
+        _check(self._L.gw_table_download_selected(self._h, snp_begin, n_rows, _p16(rows), C.byref(cb), C.byref(tb)))
+        return rows, cb.value, tb.value
 
     # ---- measurement
     def timer_start(self, stream: int | None = None):

@@ -1,0 +1,353 @@
+// gw_boost.hip -- gfx950 kernels of the pairwise (SNP x SNP) path: the
+// BOOST / KSA pre-screen of libgwaspp's computeBoost
+// (algorithms/epistasis_func.cpp:349-506) over all SNP pairs of a table.
+//
+// Reference steps restated (paths relative to /root/reference/src/libgwaspp/):
+//   k_select_cc   selectCaseControl: cases and controls compacted into dense
+//                 bit-planes, genotype/compressed_genotype_table5.cpp:443-575
+//   k_margins     computeMargins -> computeMarginalInformation,
+//                 algorithms/epistasis_func.cpp:706-721,
+//                 genotype/common_genotype_func.cpp:173-219
+//   k_boost       the O(M^2) loop of computeBoost (:393-486): margin-assisted
+//                 case/control 3x3 tables (table5.cpp:989-1150) + the
+//                 interaction measure (:424-470) + the threshold list (:482)
+//
+// Unlike the per-SNP scan this path is ALU-bound (rows are re-used M times
+// from LDS): 9 (or 4) AND+popcount per 32 samples per pair, then ~20 FP64
+// logarithms per pair.  Still no MFMA: AND-popcount has no matrix-core form
+// on CDNA4 short of expanding every bit to a 4-bit element.
+#include "gw_kernels.h"
+
+namespace gw {
+
+// ---------------------------------------------------------------------------
+// selectCaseControl: gather the members' bits into dense planes.
+// src_idx[k] = sample index of the k-th member (cases first: [0, n_case), then
+// controls: [case_pad_bits, case_pad_bits + n_ctrl)); 0xFFFFFFFF = pad bit.
+// One workgroup per SNP row, the row's two planes staged in LDS.
+// Compact row layout (32-bit words): [case p0 | case p1 | ctrl p0 | ctrl p1],
+// case planes wc words, control planes wt words.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_select_cc(const u32x4 *table, uint64_t row_stride_u,
+                                                   uint32_t plane_stride_u, uint32_t units, uint32_t n_rows,
+                                                   const uint32_t *src_idx, uint32_t wc, uint32_t wt,
+                                                   uint32_t *cc, uint64_t cc_stride_w) {
+    extern __shared__ uint32_t s_row[];  // [2][units*4]
+    const uint32_t words = units * 4u;
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(table + (uint64_t)r * row_stride_u);
+        const uint32_t *p1 = p0 + (uint64_t)plane_stride_u * 4u;
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) {
+            s_row[w] = p0[w];
+            s_row[words + w] = p1[w];
+        }
+        __syncthreads();
+        uint32_t *out = cc + (uint64_t)r * cc_stride_w;
+        const uint32_t total = wc + wt;  // output words per plane
+        for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll 8
+            for (uint32_t b = 0; b < 32u; ++b) {
+                const uint32_t s = src_idx[k * 32u + b];
+                if (s != 0xFFFFFFFFu) {
+                    lo |= ((s_row[s >> 5] >> (s & 31u)) & 1u) << b;
+                    hi |= ((s_row[words + (s >> 5)] >> (s & 31u)) & 1u) << b;
+                }
+            }
+            if (k < wc) { out[k] = lo; out[wc + k] = hi; }
+            else { out[2u * wc + (k - wc)] = lo; out[2u * wc + wt + (k - wc)] = hi; }
+        }
+    }
+}
+
+hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
+                            uint32_t *d_cc, uint64_t cc_stride_w, hipStream_t stream) {
+    if (tv.n_snps == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)(tv.n_snps < 8192 ? tv.n_snps : 8192);
+    hipLaunchKernelGGL(k_select_cc, dim3(grid), dim3(256), (size_t)tv.units * 32u, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, (uint32_t)tv.n_snps, d_src_idx, wc, wt,
+                       d_cc, cc_stride_w);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// marginal_information per SNP from the scan's counts
+// (common_genotype_func.cpp:173-219; unwritten entries are zero here)
+// ---------------------------------------------------------------------------
+__global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *mar) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t *c = counts + (size_t)r * 8u;
+    SnpMargin m;
+    uint32_t n_cases = 0, n_ctrls = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        m.cases[g] = c[g];
+        m.ctrls[g] = c[4 + g];
+        n_cases += c[g];
+        n_ctrls += c[4 + g];
+    }
+    const double n = (double)n_individs;
+    m.entropy = 0.0;
+    m.entropy_y = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t ca = m.cases[g], co = m.ctrls[g], mg = ca + co;
+        m.margins[g] = mg;
+        m.pbc[g] = m.pbc[4 + g] = m.pca[g] = m.pca[4 + g] = 0.0;
+        if (mg > 0) {
+            const double t = (double)mg / n;
+            m.entropy += -(t)*log(t);
+        }
+        if (ca > 0) {
+            const double t = (double)ca / n;
+            m.entropy_y += -(t)*log(t);
+            m.pbc[g] = (double)ca / (double)n_cases;
+            m.pca[g] = (double)ca / (double)mg;
+        }
+        if (co > 0) {
+            const double t = (double)co / n;
+            m.entropy_y += -(t)*log(t);
+            m.pbc[4 + g] = (double)co / (double)n_ctrls;
+            m.pca[4 + g] = (double)co / (double)mg;
+        }
+    }
+    mar[r] = m;
+}
+
+hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *d_mar,
+                          hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_margins, dim3((n_rows + 255u) / 256u), dim3(256), 0, stream, d_counts, n_rows,
+                       n_individs, d_mar);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// the pair kernel
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int TA = 32;  // A-block rows (SNP i) per workgroup tile
+constexpr int TB = 32;  // B-block rows (SNP j)
+constexpr int CH = 32;  // 32-bit words of every row staged per step (1024 samples)
+constexpr int LD = CH + 1;  // padded LDS row length
+
+// order-preserving map double -> uint64 for atomicMax / atomicMin
+__device__ __forceinline__ unsigned long long ordered(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+}  // namespace
+
+// computeBoost's measure for one pair from the two 3x3 tables
+// (epistasis_func.cpp:424-470); operation order as the oracle's gwo_boost_measure
+__device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                                const SnpMargin &m1, const SnpMargin &m2, int n) {
+    double tao = 0.0, im = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t x = ca[3 * a + b], y = co[3 * a + b];
+            const double pab = (double)(x + y) / (double)m2.margins[b];
+            const double t2 = (pab) * (m2.pbc[b]) * (m1.pca[a]);
+            const double t3 = (pab) * (m2.pbc[4 + b]) * (m1.pca[4 + a]);
+            tao += t2 + t3;
+            if (x > 0) {
+                const double t1 = (double)x / n;
+                im += t1 * log(t1);
+                if (t2 > 0) im += -t1 * log(t2);
+            }
+            if (y > 0) {
+                const double t1 = (double)y / n;
+                im += t1 * log(t1);
+                if (t3 > 0) im += -t1 * log(t3);
+            }
+        }
+    }
+    return (im + log(tao)) * n * 2.0;
+}
+
+struct BoostArgs {
+    const uint32_t *cc;
+    uint64_t cc_stride_w;
+    uint32_t wc, wt;
+    const SnpMargin *mar;
+    uint32_t a_begin, n_a, b_begin, n_b;
+    int n_individs;
+    double threshold;
+    BoostHit *hits;
+    unsigned long long max_hits;
+    unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
+    double *dense;              // n_a x n_b, or null
+};
+
+// One workgroup = a TA x TB tile of SNP pairs; 256 threads, each owns a 2 x 2
+// sub-tile.  For each group (cases, then controls) the rows' class vectors
+// (aa, ab, bb -- or only aa, bb when no SNP of the table has a missing call)
+// are staged through LDS CH words at a time and every thread accumulates the
+// joint counts of its four pairs with AND + v_bcnt.
+//   FAST = the reference's no-missing shortcut (table5.cpp:1066-1143): only
+//   the four homozygote corners are counted, the rest follows from the margins.
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
+    constexpr int NV = FAST ? 2 : 3;   // class vectors per row
+    constexpr int NC = FAST ? 4 : 9;   // joint counts per pair and group
+    __shared__ uint32_t sA[NV][TA][LD];
+    __shared__ uint32_t sB[NV][TB][LD];
+
+    const uint32_t a0 = a.a_begin + blockIdx.y * TA;  // first SNP i of the tile
+    const uint32_t b0 = a.b_begin + blockIdx.x * TB;  // first SNP j
+    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
+    // computeBoost only visits i < j (:396-400): tiles wholly on or below the diagonal do nothing
+    if (a0 + 1u >= min(b0 + (uint32_t)TB, b_end)) return;
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t ti = t >> 4, tj = t & 15u;  // rows 2ti, 2ti+1 of A; 2tj, 2tj+1 of B
+
+    uint32_t cnt[2][4][NC];  // [group][pair][cell]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cnt[g][p][c] = 0;
+
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t wn = g == 0 ? a.wc : a.wt;              // words per plane of this group
+        const uint32_t off = g == 0 ? 0u : 2u * a.wc;          // plane 0 of the group inside the row
+        for (uint32_t w0 = 0; w0 < wn; w0 += CH) {
+            __syncthreads();
+            // stage: (TA + TB) rows x CH words, class vectors derived on the way in
+            for (uint32_t idx = t; idx < (uint32_t)(TA + TB) * CH; idx += 256u) {
+                const uint32_t row = idx / CH, w = idx % CH;
+                const bool isB = row >= (uint32_t)TA;
+                const uint32_t snp = isB ? b0 + (row - TA) : a0 + row;
+                uint32_t p0 = 0, p1 = 0;
+                if (snp < (isB ? b_end : a_end) && w0 + w < wn) {
+                    const uint32_t *src = a.cc + (uint64_t)snp * a.cc_stride_w + off + w0 + w;
+                    p0 = src[0];
+                    p1 = src[wn];
+                }
+                const uint32_t bb = p0 & p1, aa = p0 & ~p1, ab = p1 & ~p0;
+                if (isB) {
+                    sB[0][row - TA][w] = aa;
+                    sB[NV - 1][row - TA][w] = bb;
+                    if (!FAST) sB[1][row - TA][w] = ab;
+                } else {
+                    sA[0][row][w] = aa;
+                    sA[NV - 1][row][w] = bb;
+                    if (!FAST) sA[1][row][w] = ab;
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int w = 0; w < CH; ++w) {
+                uint32_t x[2][NV], y[2][NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    x[0][v] = sA[v][2 * ti][w];
+                    x[1][v] = sA[v][2 * ti + 1][w];
+                    y[0][v] = sB[v][2 * tj][w];
+                    y[1][v] = sB[v][2 * tj + 1][w];
+                }
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj)
+#pragma unroll
+                        for (int va = 0; va < NV; ++va)
+#pragma unroll
+                            for (int vb = 0; vb < NV; ++vb)
+                                cnt[g][2 * pi + pj][NV * va + vb] += __popc(x[pi][va] & y[pj][vb]);
+            }
+        }
+    }
+
+    // per pair: tables -> measure -> outputs
+    unsigned long long n_eval = 0;
+    double vmax = -1.0e300, vmin = 1.0e300;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+#pragma unroll
+        for (int pj = 0; pj < 2; ++pj) {
+            const uint32_t i = a0 + 2 * ti + pi, j = b0 + 2 * tj + pj;
+            if (i >= a_end || j >= b_end) continue;
+            double measure = __longlong_as_double(0x7FF8000000000000ll);  // NaN: not a visited pair
+            if (i < j) {
+                const SnpMargin m1 = a.mar[i], m2 = a.mar[j];
+                uint32_t ca[9], co[9];
+                if (FAST) {
+                    // table5.cpp:1088-1106 / 1125-1143: corners counted, the rest from the margins
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const uint32_t *c4 = cnt[g][2 * pi + pj];
+                        const uint32_t *f1 = g == 0 ? m1.cases : m1.ctrls;
+                        const uint32_t *f2 = g == 0 ? m2.cases : m2.ctrls;
+                        uint32_t *o = g == 0 ? ca : co;
+                        o[0] = c4[0]; o[2] = c4[1]; o[6] = c4[2]; o[8] = c4[3];
+                        o[1] = f1[0] - o[0] - o[2];        // AA_Bb
+                        o[7] = f1[2] - o[8] - o[6];        // aa_Bb
+                        o[3] = f2[0] - o[0] - o[6];        // Aa_BB
+                        o[5] = f2[2] - o[2] - o[8];        // Aa_bb
+                        o[4] = f2[1] - o[1] - o[7];        // Aa_Bb
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        ca[c] = cnt[0][2 * pi + pj][c];
+                        co[c] = cnt[1][2 * pi + pj][c];
+                    }
+                }
+                measure = boost_measure(ca, co, m1, m2, a.n_individs);
+                ++n_eval;
+                vmax = fmax(vmax, measure);
+                vmin = fmin(vmin, measure);
+                if (measure > a.threshold) {  // :482-484
+                    const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+                    if (slot < a.max_hits) {
+                        BoostHit h;
+                        h.snp_a = i;
+                        h.snp_b = j;
+                        h.measure = measure;
+                        a.hits[slot] = h;
+                    }
+                }
+            }
+            if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
+        }
+    }
+    // tile tallies: wave reduce, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_xor(n_eval, off, 64);
+        vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+        vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
+    }
+    if ((t & 63u) == 0 && n_eval) {
+        atomicAdd(&a.tally[1], n_eval);
+        atomicMax(&a.tally[2], ordered(vmax));
+        atomicMin(&a.tally[3], ordered(vmin));
+    }
+}
+
+hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
+                        const SnpMargin *d_mar, uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
+                        uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
+                        unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
+                        bool fast, hipStream_t stream) {
+    if (n_a == 0 || n_b == 0) return hipSuccess;
+    BoostArgs a;
+    a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar;
+    a.a_begin = a_begin; a.n_a = n_a; a.b_begin = b_begin; a.n_b = n_b;
+    a.n_individs = (int)n_individs; a.threshold = threshold;
+    a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
+    const dim3 grid((n_b + TB - 1) / TB, (n_a + TA - 1) / TA);
+    if (fast) hipLaunchKernelGGL(k_boost<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_boost<false>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace gw

@@ -64,6 +64,15 @@ struct gw_table {
     size_t scratch64_bytes = 0;
     uint32_t *d_misc = nullptr;  // 16 x uint32 (probe sink, phenotype counts)
 
+    // pairwise path: selectCaseControl's compacted planes + per-SNP margins
+    uint32_t *d_cc = nullptr;
+    uint64_t cc_stride_w = 0;
+    uint32_t wc = 0, wt = 0;
+    gw::SnpMargin *d_mar = nullptr;
+    bool selected_valid = false, any_missing = true;
+    uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
+    unsigned long long *d_tally = nullptr;
+
     // rows packed by gw_table_add_genotype_row, waiting for the next flush
     std::vector<uint16_t> pending;
     uint64_t pending_begin = 0;
@@ -276,6 +285,9 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_scratch32) (void)hipFree(t->d_scratch32);
     if (t->d_scratch64) (void)hipFree(t->d_scratch64);
     if (t->d_misc) (void)hipFree(t->d_misc);
+    if (t->d_cc) (void)hipFree(t->d_cc);
+    if (t->d_mar) (void)hipFree(t->d_mar);
+    if (t->d_tally) (void)hipFree(t->d_tally);
     if (t->ev_start) (void)hipEventDestroy(t->ev_start);
     if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -309,6 +321,7 @@ int gw_table_upload_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const
         const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, n_rows - done);
         GW_HIP(hipMemcpy2DAsync(t->d_staging, ref_bytes, src + done * row_stride_bytes, row_stride_bytes,
                                 ref_bytes, n, hipMemcpyHostToDevice, t->stream));
+        t->selected_valid = false;
         GW_HIP(gw::launch_restride_in(t->tv, snp_begin + done, n, t->d_staging, ref_bytes, layout,
                                       ref_blocks, t->stream));
         GW_HIP(hipStreamSynchronize(t->stream));
@@ -419,6 +432,7 @@ int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uin
     int rc = use_device(t);
     if (rc) return rc;
     t->pending_rows = 0;
+    t->selected_valid = false;
     GW_HIP(gw::launch_simulate(t->tv, seed, snp_global_begin, missing_q16, t->compute_units * 8, t->stream));
     GW_HIP(hipStreamSynchronize(t->stream));
     // alleles A (major) / C (minor), all three genotypes: order 7, AA=0, AC=1, CC=5
@@ -446,6 +460,7 @@ int gw_table_simulate_phenotype(gw_table *t, uint64_t seed) {
     t->case_count = counts[0];
     t->ctrl_count = counts[1];
     t->masks_set = true;
+    t->selected_valid = false;
     return GW_OK;
 }
 
@@ -469,6 +484,7 @@ int gw_table_set_case_control(gw_table *t, const uint16_t *case_stream, const ui
     t->case_count = case_count;
     t->ctrl_count = ctrl_count;
     t->masks_set = true;
+    t->selected_valid = false;
     return GW_OK;
 }
 
@@ -581,6 +597,196 @@ int gw_pair_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, ui
 int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_t n_pairs, uint32_t *out_case,
                                      uint32_t *out_ctrl) {
     return pair_common(t, pairs, n_pairs, out_case, out_ctrl, true);
+}
+
+
+// ------------------------------------------------------- pairwise / BOOST path
+
+namespace {
+
+// members of a stream mask in ascending sample order
+void mask_members(const std::vector<uint16_t> &mask, uint32_t n_samples, const std::vector<uint16_t> *exclude,
+                  std::vector<uint32_t> &out) {
+    out.clear();
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const uint16_t bit = (uint16_t)(1u << (s & 15u));
+        if (!(mask[s >> 4] & bit)) continue;
+        if (exclude && ((*exclude)[s >> 4] & bit)) continue;  // a case wins over a control (table5.cpp:531-548)
+        out.push_back(s);
+    }
+}
+
+// selectCaseControl + computeMargins on the device (idempotent until data or masks change)
+int ensure_selected(gw_table *t) {
+    if (!t->masks_set)
+        return fail(GW_E_STATE, "gw_table_set_case_control must be called before a case/control pair analysis");
+    int rc = gw_table_flush(t);
+    if (rc) return rc;
+    if (t->selected_valid) return GW_OK;
+    if ((rc = use_device(t))) return rc;
+    const uint64_t m = t->tv.n_snps;
+    std::vector<uint32_t> cases, ctrls;
+    mask_members(t->h_case, t->geo.n_samples, nullptr, cases);
+    mask_members(t->h_ctrl, t->geo.n_samples, &t->h_case, ctrls);
+    // dense planes padded to whole 16-byte units
+    const uint32_t wc = std::max<uint32_t>(4u, (uint32_t)((cases.size() + 127u) / 128u) * 4u);
+    const uint32_t wt = std::max<uint32_t>(4u, (uint32_t)((ctrls.size() + 127u) / 128u) * 4u);
+    std::vector<uint32_t> src((size_t)(wc + wt) * 32u, 0xFFFFFFFFu);
+    std::copy(cases.begin(), cases.end(), src.begin());
+    std::copy(ctrls.begin(), ctrls.end(), src.begin() + (size_t)wc * 32u);
+    const uint64_t stride_w = 2ull * (wc + wt);
+    if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
+    if (t->d_mar) { GW_HIP(hipFree(t->d_mar)); t->d_mar = nullptr; }
+    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long)));
+    if (m) {
+        GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
+        GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
+    }
+    uint32_t *d_src = nullptr;
+    GW_HIP(hipMalloc((void **)&d_src, src.size() * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = gw::launch_select_cc(t->tv, d_src, wc, wt, t->d_cc, stride_w, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    (void)hipFree(d_src);
+    if (e != hipSuccess) return fail(GW_E_HIP, "selectCaseControl on the device: %s", hipGetErrorString(e));
+    t->wc = wc;
+    t->wt = wt;
+    t->cc_stride_w = stride_w;
+    // computeMargins: the per-SNP case/control counts of the scan kernel -> marginal_information.
+    // A sample in both masks is a case only here (as in the compacted rows), so the counts come
+    // from masks with the overlap removed.
+    std::vector<uint32_t> counts(m * GW_N_COUNTS);
+    if (m) {
+        std::vector<uint16_t> ctrl_only(t->h_ctrl);
+        for (size_t b = 0; b < ctrl_only.size(); ++b) ctrl_only[b] = (uint16_t)(ctrl_only[b] & ~t->h_case[b]);
+        const std::vector<uint16_t> keep_ctrl(t->h_ctrl);
+        const uint32_t keep_nc = t->case_count, keep_nt = t->ctrl_count;
+        const bool overlap = ctrl_only != keep_ctrl;
+        if (overlap) {
+            rc = gw_table_set_case_control(t, t->h_case.data(), ctrl_only.data(), (uint32_t)ctrl_only.size(),
+                                           (uint32_t)cases.size(), (uint32_t)ctrls.size());
+            if (rc) return rc;
+        }
+        rc = gw_scan_case_control(t, 0, m, counts.data(), nullptr);
+        if (overlap) {
+            const std::vector<uint16_t> keep_case(t->h_case);
+            int rc2 = gw_table_set_case_control(t, keep_case.data(), keep_ctrl.data(), (uint32_t)keep_ctrl.size(),
+                                                keep_nc, keep_nt);
+            if (!rc) rc = rc2;
+        }
+        if (rc) return rc;
+        GW_HIP(gw::launch_margins(t->d_scratch32, (uint32_t)m, (uint32_t)(cases.size() + ctrls.size()), t->d_mar,
+                                  t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));
+    }
+    t->sel_individs = (uint32_t)(cases.size() + ctrls.size());
+    t->any_missing = false;
+    for (uint64_t r = 0; r < m && !t->any_missing; ++r)
+        t->any_missing = counts[r * 8 + 3] != 0 || counts[r * 8 + 7] != 0;
+    t->selected_valid = true;
+    return GW_OK;
+}
+
+double from_ordered(unsigned long long u) {
+    u = (u & 0x8000000000000000ull) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    double d;
+    std::memcpy(&d, &u, sizeof d);
+    return d;
+}
+
+int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
+                 gw_boost_hit *hits, uint64_t max_hits, uint64_t *n_hits, uint64_t *n_pairs, double *vmax,
+                 double *vmin, double *dense) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = check_range(t, a_begin, n_a);
+    if (rc) return rc;
+    if ((rc = check_range(t, b_begin, n_b))) return rc;
+    if (t->tv.n_snps > 0xFFFFFFFFull) return fail(GW_E_RANGE, "pair analysis supports up to 2^32-1 SNPs");
+    if ((rc = ensure_selected(t))) return rc;
+    if ((rc = use_device(t))) return rc;
+    const unsigned long long init[4] = {0ull, 0ull, 0ull, ~0ull};
+    GW_HIP(hipMemcpyAsync(t->d_tally, init, sizeof init, hipMemcpyHostToDevice, t->stream));
+    gw::BoostHit *d_hits = nullptr;
+    double *d_dense = nullptr;
+    if (max_hits) GW_HIP(hipMalloc((void **)&d_hits, max_hits * sizeof(gw::BoostHit)));
+    hipError_t e = hipSuccess;
+    if (dense && n_a && n_b) {
+        e = hipMalloc((void **)&d_dense, n_a * n_b * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0xFF, n_a * n_b * sizeof(double), t->stream);  // NaN
+    }
+    if (e == hipSuccess)
+        e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, (uint32_t)a_begin, (uint32_t)n_a,
+                             (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
+                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream);
+    unsigned long long tally[4] = {0, 0, 0, ~0ull};
+    if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess && hits && max_hits) {
+        const uint64_t n = std::min<uint64_t>(tally[0], max_hits);
+        if (n) e = hipMemcpy(hits, d_hits, n * sizeof(gw::BoostHit), hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess && dense && d_dense) e = hipMemcpy(dense, d_dense, n_a * n_b * sizeof(double), hipMemcpyDeviceToHost);
+    if (d_hits) (void)hipFree(d_hits);
+    if (d_dense) (void)hipFree(d_dense);
+    if (e != hipSuccess) return fail(GW_E_HIP, "BOOST pre-screen: %s", hipGetErrorString(e));
+    if (n_hits) *n_hits = tally[0];
+    if (n_pairs) *n_pairs = tally[1];
+    if (vmax) *vmax = tally[1] ? from_ordered(tally[2]) : 0.0;
+    if (vmin) *vmin = tally[1] ? from_ordered(tally[3]) : 0.0;
+    return GW_OK;
+}
+
+}  // namespace
+
+int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
+                    gw_boost_hit *hits, uint64_t max_hits, uint64_t *n_hits, uint64_t *n_pairs,
+                    double *max_measure, double *min_measure) {
+    static_assert(sizeof(gw_boost_hit) == sizeof(gw::BoostHit), "hit record layout");
+    if (max_hits && !hits) return fail(GW_E_INVALID, "hits is NULL");
+    return boost_common(t, a_begin, n_a, b_begin, n_b, threshold, hits, max_hits, n_hits, n_pairs, max_measure,
+                        min_measure, nullptr);
+}
+
+int gw_boost_measures(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double *measures) {
+    if (!measures && n_a && n_b) return fail(GW_E_INVALID, "measures is NULL");
+    if (n_a * n_b > (1ull << 28)) return fail(GW_E_RANGE, "block too large for the dense form");
+    return boost_common(t, a_begin, n_a, b_begin, n_b, 1.0e300, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                        measures);
+}
+
+int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint16_t *rows, uint32_t *case_blocks,
+                               uint32_t *ctrl_blocks) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    int rc = check_range(t, snp_begin, n_rows);
+    if (rc) return rc;
+    if ((rc = ensure_selected(t))) return rc;
+    // reference geometry of the compacted rows (table5.cpp:449-468); a sample in both sets is a case
+    std::vector<uint32_t> cases, ctrls;
+    mask_members(t->h_case, t->geo.n_samples, nullptr, cases);
+    mask_members(t->h_ctrl, t->geo.n_samples, &t->h_case, ctrls);
+    const uint32_t cb = (((uint32_t)cases.size() / 16u + 1u) + 3u) & ~3u;
+    const uint32_t tb = (((uint32_t)ctrls.size() / 16u + 1u) + 3u) & ~3u;
+    if (case_blocks) *case_blocks = cb;
+    if (ctrl_blocks) *ctrl_blocks = tb;
+    if (!rows || !n_rows) return GW_OK;
+    std::vector<uint32_t> buf(n_rows * t->cc_stride_w);
+    GW_HIP(hipMemcpy(buf.data(), t->d_cc + snp_begin * t->cc_stride_w, buf.size() * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+    const size_t out_stride = 2u * (size_t)(cb + tb);
+    std::memset(rows, 0, n_rows * out_stride * sizeof(uint16_t));
+    auto copy_plane = [](uint16_t *dst, uint32_t dst_blocks, const uint32_t *src, uint32_t src_words) {
+        const uint32_t n = std::min<uint32_t>(dst_blocks, src_words * 2u);
+        std::memcpy(dst, src, (size_t)n * sizeof(uint16_t));  // little-endian: same bit order
+    };
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        const uint32_t *src = buf.data() + r * t->cc_stride_w;
+        uint16_t *dst = rows + r * out_stride;
+        copy_plane(dst, cb, src, t->wc);
+        copy_plane(dst + cb, cb, src + t->wc, t->wc);
+        copy_plane(dst + 2u * cb, tb, src + 2u * t->wc, t->wt);
+        copy_plane(dst + 2u * cb + tb, tb, src + 2u * t->wc + t->wt, t->wt);
+    }
+    return GW_OK;
 }
 
 // ------------------------------------------------------------ measurement

@@ -79,4 +79,30 @@ hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl
 hipError_t launch_stream_probe(const u32x4 *base, uint64_t n_units, uint32_t *d_sink,
                                int grid_blocks, hipStream_t stream);
 
+// ---- pairwise path (gw_boost.hip) ------------------------------------------
+// marginal_information of one SNP (genotype/common_genotype.h:101-106)
+struct SnpMargin {
+    uint32_t margins[4], cases[4], ctrls[4];
+    double entropy, entropy_y;
+    double pbc[8];  // P(genotype | status): cases[4], controls[4]
+    double pca[8];  // P(status | genotype)
+};
+struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
+    uint32_t snp_a, snp_b;
+    double measure;
+};
+
+// selectCaseControl compaction (table5.cpp:443-575) of the whole table
+hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
+                            uint32_t *d_cc, uint64_t cc_stride_w, hipStream_t stream);
+hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *d_mar,
+                          hipStream_t stream);
+// BOOST pre-screen of the SNP block pair [a_begin,+n_a) x [b_begin,+n_b), pairs i < j
+// d_tally: [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
+hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
+                        const SnpMargin *d_mar, uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
+                        uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
+                        unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
+                        bool fast, hipStream_t stream);
+
 }  // namespace gw

@@ -793,6 +793,61 @@ void gwo_sim_phenotype_stream(uint64_t seed, const gwo_geom *g, uint16_t *cs, ui
 }
 
 /* ------------------------------------------------------------------------ */
+/* BOOST / KSA pre-screen, algorithms/epistasis_func.cpp:404-470             */
+/* ------------------------------------------------------------------------ */
+
+double gwo_boost_measure(const uint32_t ca_tab[16], const uint32_t co_tab[16], const gwo_marginal *m1,
+                         const gwo_marginal *m2, uint32_t n_individs) {
+    const uint32_t mar2[4] = {m2->margins.aa, m2->margins.ab, m2->margins.bb, m2->margins.xx};
+    const int n = (int)n_individs; /* an int in the reference (:352-354) */
+    double tao = 0.0, im = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) { /* the xx column/row of the 4x4 tables is skipped (:436-445) */
+            const uint32_t ca = ca_tab[4 * a + b], co = co_tab[4 * a + b];
+            const double pab = (double)(ca + co) / (double)mar2[b];
+            const double t2 = (pab) * (m2->pbc[b]) * (m1->pca[a]);
+            const double t3 = (pab) * (m2->pbc[4 + b]) * (m1->pca[4 + a]);
+            tao += t2 + t3;
+            if (ca > 0) {
+                const double t1 = (double)ca / n;
+                im += t1 * log(t1);
+                if (t2 > 0) im += -t1 * log(t2);
+            }
+            if (co > 0) {
+                const double t1 = (double)co / n;
+                im += t1 * log(t1);
+                if (t3 > 0) im += -t1 * log(t3);
+            }
+        }
+    }
+    return (im + log(tao)) * n * 2.0;
+}
+
+void gwo_boost_all_pairs(const uint16_t *table, uint32_t n_snps, const gwo_geom *g, const uint16_t *cs,
+                         const uint16_t *ct, uint32_t case_count, uint32_t ctrl_count, double *measures) {
+    const uint32_t n_individs = case_count + ctrl_count;
+    gwo_marginal *mar = (gwo_marginal *)calloc(n_snps, sizeof(gwo_marginal));
+    for (uint32_t i = 0; i < n_snps; ++i) { /* computeMargins, epistasis_func.cpp:706-721 */
+        gwo_freq ca, co;
+        gwo_stream_cc_dist(table + (size_t)i * g->blocks_per_row, g, cs, ct, case_count, ctrl_count, &ca, &co);
+        gwo_marginal_information(&ca, &co, n_individs, &mar[i]);
+    }
+    const uint32_t pad = g->words * 64u;
+    size_t k = 0;
+    for (uint32_t i = 0; i < n_snps; ++i)
+        for (uint32_t j = i + 1; j < n_snps; ++j) {
+            uint32_t a[16], b[16];
+            gwo_stream_cc_contingency(table + (size_t)i * g->blocks_per_row, table + (size_t)j * g->blocks_per_row,
+                                      g, cs, ct, a, b);
+            /* margin-assisted getter: exact member tables (table5.cpp:1031,1062) */
+            a[15] -= pad - case_count;
+            b[15] -= pad - ctrl_count;
+            measures[k++] = gwo_boost_measure(a, b, &mar[i], &mar[j], n_individs);
+        }
+    free(mar);
+}
+
+/* ------------------------------------------------------------------------ */
 /* pairwise LLR, src/test/pairwise.c:50-133                                  */
 /* ------------------------------------------------------------------------ */
 

@@ -198,6 +198,20 @@ void gwo_sim_phenotype_stream(uint64_t seed, const gwo_geom *g,
 /* the per-SNP minor-allele probability the simulator drew, as p*1e5. */
 uint32_t gwo_sim_snp_p_e5(uint64_t seed, uint64_t snp);
 
+/* ---- BOOST / KSA pre-screen (algorithms/epistasis_func.cpp:349-506; NEXT row) ----
+ * The interaction measure of one SNP pair as computeBoost evaluates it
+ * (:424-470) from the margin-assisted 4x4 case / control tables
+ * (table5.cpp:989-1150) and the two SNPs' marginal_information.  Entries the
+ * reference leaves uninitialised (quirk Q6) are zero here. */
+double gwo_boost_measure(const uint32_t case_tab[16], const uint32_t ctrl_tab[16],
+                         const gwo_marginal *m1, const gwo_marginal *m2, uint32_t n_individs);
+/* All pairs i < j of a stream-layout table: measures[M*(M-1)/2] in the order
+ * (0,1),(0,2),...,(1,2),...  Tables are the exact member tables the
+ * margin-assisted getter returns. */
+void gwo_boost_all_pairs(const uint16_t *table, uint32_t n_snps, const gwo_geom *g,
+                         const uint16_t *case_stream, const uint16_t *ctrl_stream,
+                         uint32_t case_count, uint32_t ctrl_count, double *measures);
+
 /* ---- pairwise LLR known-answer test (src/test/pairwise.c:50-133; NEXT row) ---- */
 double gwo_pairwise_llr(const uint32_t case_tab[9], const uint32_t ctrl_tab[9]);
 

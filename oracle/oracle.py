@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
         L.gwo_sim_phenotype_stream.argtypes = [C.c_uint64, gp, u16p, u16p, u32p, u32p]
         L.gwo_sim_snp_p_e5.argtypes = [C.c_uint64, C.c_uint64]
         L.gwo_sim_snp_p_e5.restype = C.c_uint32
+        L.gwo_boost_measure.argtypes = [u32p, u32p, C.POINTER(Marginal), C.POINTER(Marginal), C.c_uint32]
+        L.gwo_boost_measure.restype = C.c_double
+        L.gwo_boost_all_pairs.argtypes = [u16p, C.c_uint32, gp, u16p, u16p, C.c_uint32, C.c_uint32, f64p]
         L.gwo_pairwise_llr.argtypes = [u32p, u32p]
         L.gwo_pairwise_llr.restype = C.c_double
         _lib = L
@@ -274,6 +277,21 @@ def marginal_information(cases, ctrls, n_individs):
 def assoc_stats(cases, ctrls) -> np.ndarray:
     out = np.zeros(N_STATS, dtype=np.float64)
     lib().gwo_assoc_stats(C.byref(Freq(*cases)), C.byref(Freq(*ctrls)), _pf64(out))
+    return out
+
+
+def boost_measure(case16, ctrl16, m1: "Marginal", m2: "Marginal", n_individs: int) -> float:
+    a = np.ascontiguousarray(np.asarray(case16, dtype=np.uint32).reshape(16))
+    b = np.ascontiguousarray(np.asarray(ctrl16, dtype=np.uint32).reshape(16))
+    return lib().gwo_boost_measure(_p32(a), _p32(b), C.byref(m1), C.byref(m2), n_individs)
+
+
+def boost_all_pairs(table, g, case_stream, ctrl_stream, case_count, ctrl_count) -> np.ndarray:
+    table = np.ascontiguousarray(table, dtype=np.uint16)
+    m = table.shape[0]
+    out = np.zeros(m * (m - 1) // 2, dtype=np.float64)
+    lib().gwo_boost_all_pairs(_p16(table), m, C.byref(g), _p16(case_stream), _p16(ctrl_stream),
+                              case_count, ctrl_count, _pf64(out))
     return out
 
 

@@ -1,0 +1,133 @@
+"""Pairwise path on the GPU vs the oracle: selectCaseControl's compacted rows
+(table5.cpp:443-575), the BOOST / KSA interaction measure of every SNP pair
+(algorithms/epistasis_func.cpp:349-506) and its threshold list.  The measure
+itself is pinned to the reference's pairwise.c known-answer tables in
+tests/test_oracle_arith.py.  Needs a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libgwaspp_amd as gw
+
+pytestmark = pytest.mark.gpu
+
+
+def _codes(rng, m, n, p_missing):
+    q = rng.uniform(0.05, 0.5, size=(m, 1))
+    a = rng.random((m, n)) < q
+    b = rng.random((m, n)) < q
+    codes = np.where(a & b, 3, np.where(a | b, 2, 1)).astype(np.uint8)
+    if p_missing:
+        codes[rng.random((m, n)) < p_missing] = 0
+    return codes
+
+
+def _masks(oracle, rng, n, neither=0.1):
+    u = rng.random(n)
+    cases = np.flatnonzero(u < 0.5 - neither / 2).astype(np.int32)
+    ctrls = np.flatnonzero(u >= 0.5 + neither / 2).astype(np.int32)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    return cs, ct, nc, nt
+
+
+def _pair_matrix(flat, m):
+    out = np.full((m, m), np.nan)
+    k = 0
+    for i in range(m):
+        for j in range(i + 1, m):
+            out[i, j] = flat[k]
+            k += 1
+    return out
+
+
+@pytest.mark.parametrize("n,m,p_missing", [(70, 9, 0.0), (1000, 40, 0.0), (1000, 40, 0.03), (4097, 70, 0.0),
+                                           (4097, 33, 0.01), (129, 65, 0.05), (20_000, 48, 0.0)])
+def test_boost_measures_vs_oracle(oracle, n, m, p_missing):
+    if gw.device_count() == 0:
+        pytest.fail("no HIP device visible")
+    rng = np.random.default_rng(n * 31 + m)
+    ts = oracle.pack_codes(_codes(rng, m, n, p_missing), "stream")
+    gs = oracle.geometry_stream(n)
+    cs, ct, nc, nt = _masks(oracle, rng, n)
+    want = _pair_matrix(oracle.boost_all_pairs(ts, gs, cs, ct, nc, nt), m)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        got = t.boost_measures(0, m, 0, m)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-10, atol=1e-10)
+        # block form: any rectangle of the pair space gives the same numbers
+        a0, na, b0, nb = 1, m // 2, m // 3, m - m // 3
+        blk = t.boost_measures(a0, na, b0, nb)
+        sub = want[a0:a0 + na, b0:b0 + nb]
+        ok = ~np.isnan(sub)
+        assert np.array_equal(np.isnan(blk), ~ok)
+        np.testing.assert_allclose(blk[ok], sub[ok], rtol=1e-10, atol=1e-10)
+        # threshold list
+        finite = want[~np.isnan(want)]
+        thr = float(np.median(finite))
+        hits, n_hits, n_pairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=thr)
+        assert n_pairs == m * (m - 1) // 2
+        assert n_hits == int((finite > thr).sum()) == len(hits)
+        for h in hits:
+            assert h["snp_a"] < h["snp_b"]
+            assert h["measure"] == got[h["snp_a"], h["snp_b"]] and h["measure"] > thr
+        assert vmax == np.nanmax(got) and vmin == np.nanmin(got)
+        # a capped list reports the full count
+        few, n_hits2, *_ = t.boost_screen(0, m, 0, m, threshold=thr, max_hits=3)
+        assert n_hits2 == n_hits and len(few) == min(3, n_hits)
+
+
+@pytest.mark.parametrize("n", [70, 1000, 4097])
+def test_select_case_control_compaction(oracle, n):
+    """gw_table_download_selected == the reference's m_cases_controls rows."""
+    m = 7
+    rng = np.random.default_rng(n)
+    ts = oracle.pack_codes(_codes(rng, m, n, 0.04), "stream")
+    gs = oracle.geometry_stream(n)
+    cs, ct, nc, nt = _masks(oracle, rng, n)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        rows, cb, tb = t.download_selected(0, m)
+        ocb, otb = C.c_uint32(), C.c_uint32()
+        oracle.lib().gwo_compact_geometry(nc, nt, C.byref(ocb), C.byref(otb))
+        assert (cb, tb) == (ocb.value, otb.value)
+        for r in range(m):
+            want = np.zeros(2 * (cb + tb), np.uint16)
+            p16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint16))
+            oracle.lib().gwo_stream_compact_row(p16(ts[r]), C.byref(gs), p16(cs), p16(ct), cb, tb, p16(want))
+            assert np.array_equal(rows[r], want)
+
+
+def test_boost_on_simulated_table_matches_oracle_and_finds_planted_pair(oracle):
+    """End to end on the synthetic generator, plus one planted interaction that
+    must come out of the threshold list."""
+    n, m, seed = 6000, 90, 0x5EED
+    rng = np.random.default_rng(5)
+    table, gs = oracle.sim_table_stream(seed, 0, m, n)
+    cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+    # plant: make SNP 7 x SNP 11 jointly predictive of case status
+    is_case = np.unpackbits(cs.view(np.uint8), bitorder="little")[:n].astype(bool)
+    codes = np.array([[oracle.lib().gwo_stream_code_at(table[r].ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                       C.byref(gs), c) for c in range(n)] for r in (7, 11)],
+                     dtype=np.uint8)
+    a = rng.integers(1, 4, size=n).astype(np.uint8)
+    b = rng.integers(1, 4, size=n).astype(np.uint8)
+    flip = is_case & (rng.random(n) < 0.6)
+    b[flip] = a[flip]                       # cases: the two genotypes agree far more often
+    codes[0], codes[1] = a, b
+    planted = oracle.pack_codes(codes, "stream")
+    table[7], table[11] = planted[0], planted[1]
+    want = _pair_matrix(oracle.boost_all_pairs(table, gs, cs, ct, nc, nt), m)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, table)
+        t.set_case_control(cs, ct, nc, nt)
+        hits, n_hits, n_pairs, vmax, _ = t.boost_screen(0, m, 0, m, threshold=30.0)   # the reference's threshold
+        assert n_pairs == m * (m - 1) // 2
+        assert (7, 11) in {(int(h["snp_a"]), int(h["snp_b"])) for h in hits}
+        assert n_hits == int((want[~np.isnan(want)] > 30.0).sum())
+        assert vmax == pytest.approx(np.nanmax(want), rel=1e-10)

@@ -116,3 +116,19 @@ def test_simulator_shape(oracle):
     aa, ab, bb, xx = oracle.stream_dist(t2[0], g)
     miss = n - (aa + ab + bb)
     assert 100 < miss < 320
+
+
+@pytest.mark.parametrize("name,cs,ct,llr", PAIRWISE_KAT)
+def test_boost_measure_equals_pairwise_llr(oracle, name, cs, ct, llr):
+    """computeBoost's interaction measure (epistasis_func.cpp:424-470) is the
+    same statistic as src/test/pairwise.c's 2*log-likelihood ratio, so the five
+    literal tables of pairwise.c:20-37 pin it too."""
+    cs, ct = np.array(cs, dtype=np.uint32), np.array(ct, dtype=np.uint32)
+    case16, ctrl16 = np.zeros((4, 4), np.uint32), np.zeros((4, 4), np.uint32)
+    case16[:3, :3], ctrl16[:3, :3] = cs, ct
+    n = int(cs.sum() + ct.sum())
+    m1 = oracle.marginal_information(tuple(int(v) for v in cs.sum(axis=1)) + (0,),
+                                     tuple(int(v) for v in ct.sum(axis=1)) + (0,), n)
+    m2 = oracle.marginal_information(tuple(int(v) for v in cs.sum(axis=0)) + (0,),
+                                     tuple(int(v) for v in ct.sum(axis=0)) + (0,), n)
+    assert oracle.boost_measure(case16, ctrl16, m1, m2, n) == pytest.approx(llr, rel=1e-10)
