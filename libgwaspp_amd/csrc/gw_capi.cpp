@@ -96,7 +96,8 @@ gw::ScanShape scan_shape(const gw_table *t) {
     //   masks fill more than half the LDS (N > ~320 k): one 512-thread workgroup per CU,
     //     2 units per lane per plane in flight -- fewer, fatter streams read HBM best;
     //   masks fit several times: 1024-thread workgroups, 1 unit in flight, up to 4 per CU;
-    //   masks do not fit (N > ~650 k): read through L2, 4 units in flight.
+    //   masks do not fit (N > ~650 k): read through L2, 4 units in flight;
+    //   short rows (N <= ~32 k): 256-thread workgroups, 8 per CU.
     gw::ScanShape sh{};
     sh.pipeline = t->opt_pipeline;
     sh.nontemporal = t->opt_nt;
@@ -114,8 +115,9 @@ gw::ScanShape scan_shape(const gw_table *t) {
     sh.lds_bytes = lds ? need : 0;
     sh.unroll = unroll;
     const int lds_limit = lds ? (int)(t->lds_cap / need) : 8;
-    int threads = t->opt_threads ? t->opt_threads : (one_per_cu ? 512 : 1024);
-    int per_cu = t->opt_blocks_per_cu ? t->opt_blocks_per_cu : (one_per_cu ? 1 : 4);
+    const bool short_rows = t->tv.units <= 256u;  // N <= ~32 k: rows of one or two wave-steps
+    int threads = t->opt_threads ? t->opt_threads : (one_per_cu ? 512 : (short_rows ? 256 : 1024));
+    int per_cu = t->opt_blocks_per_cu ? t->opt_blocks_per_cu : (one_per_cu ? 1 : (short_rows ? 8 : 4));
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
     sh.grid_blocks = t->compute_units * per_cu;

@@ -154,13 +154,34 @@ struct ScanArgs {
     double *stats;
 };
 
+// ---- row epilogue shared by both scan kernels (table5.cpp:647-653 + section 5 of DESIGN.md)
+__device__ __forceinline__ void finish_row(const ScanArgs &a, uint32_t r, const uint32_t (&s)[6]) {
+    uint32_t ca[4], co[4];
+    ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
+    ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
+    co[2] = s[5]; co[0] = s[3] - s[5]; co[1] = s[4] - s[5];
+    co[3] = a.ctrl_count - co[0] - co[1] - co[2];
+    u32x4 *out = reinterpret_cast<u32x4 *>(a.counts + (size_t)r * 8u);
+    u32x4 v0 = {ca[0], ca[1], ca[2], ca[3]};
+    u32x4 v1 = {co[0], co[1], co[2], co[3]};
+    out[0] = v0;
+    out[1] = v1;
+    if (a.stats) {
+        double st[8];
+        assoc_stats(ca, co, st);
+        double *so = a.stats + (size_t)r * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) so[j] = st[j];
+    }
+}
+
 // Persistent workgroups: the grid is (CUs x workgroups-per-CU); each wave
 // walks rows gwave, gwave + total_waves, ...  Per row a lane streams 16-byte
 // units lane, lane+64, ... of both bit-planes (two 1-KiB coalesced
 // wave-loads per step, UNROLL steps in flight), ANDs them with the case and
 // control masks (staged once per workgroup in LDS, or read through L2 when
-// they do not fit) and keeps six 32-bit popcounts; a wave-level shuffle
-// reduction and lane 0's FP64 epilogue finish the row.
+// they do not fit) and keeps six 32-bit popcounts; a DPP wave reduction ends
+// the row, and the FP64 epilogue runs for 64 finished rows at a time.
 template <int UNROLL, bool MASK_LDS, bool NT>
 __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     extern __shared__ u32x4 lds_masks[];  // [2][units] when MASK_LDS
@@ -183,6 +204,12 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     const uint32_t total_waves = gridDim.x * waves_per_block;
     constexpr uint32_t STEP = 64u * UNROLL;
     const uint32_t full = (units / STEP) * STEP;
+
+    // Row results are parked one per lane (lane k keeps the k-th row this wave
+    // finished) and the FP64 epilogue runs once per 64 rows with every lane
+    // busy, instead of once per row on lane 0 while the wave's loads drain.
+    uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t my_row = 0xFFFFFFFFu, slot = 0;
 
     for (uint32_t r = gwave; r < a.n_rows; r += total_waves) {
         const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
@@ -209,53 +236,20 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
             acc_unit(A, B, mcase[u], mctrl[u], c0);
         }
 
-        uint32_t s[6];
+        const bool park = lane == slot;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) s[j] = wave_sum(c0[j] + c1[j]);
-
-        if (lane == 0) {
-            // table5.cpp:647-653
-            uint32_t ca[4], co[4];
-            ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
-            ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
-            co[2] = s[5]; co[0] = s[3] - s[5]; co[1] = s[4] - s[5];
-            co[3] = a.ctrl_count - co[0] - co[1] - co[2];
-            u32x4 *out = reinterpret_cast<u32x4 *>(a.counts + (size_t)r * 8u);
-            u32x4 v0 = {ca[0], ca[1], ca[2], ca[3]};
-            u32x4 v1 = {co[0], co[1], co[2], co[3]};
-            out[0] = v0;
-            out[1] = v1;
-            if (a.stats) {
-                double st[8];
-                assoc_stats(ca, co, st);
-                double *so = a.stats + (size_t)r * 8u;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) so[j] = st[j];
-            }
+        for (int j = 0; j < 6; ++j) {
+            const uint32_t total = wave_sum_dpp(c0[j] + c1[j]);  // wave-uniform
+            mine[j] = park ? total : mine[j];
+        }
+        my_row = park ? r : my_row;
+        if (++slot == 64u) {
+            finish_row(a, my_row, mine);  // all 64 lanes hold a row
+            my_row = 0xFFFFFFFFu;
+            slot = 0;
         }
     }
-}
-
-
-// ---- row epilogue shared by both scan kernels (table5.cpp:647-653 + section 5 of DESIGN.md)
-__device__ __forceinline__ void finish_row(const ScanArgs &a, uint32_t r, const uint32_t (&s)[6]) {
-    uint32_t ca[4], co[4];
-    ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
-    ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
-    co[2] = s[5]; co[0] = s[3] - s[5]; co[1] = s[4] - s[5];
-    co[3] = a.ctrl_count - co[0] - co[1] - co[2];
-    u32x4 *out = reinterpret_cast<u32x4 *>(a.counts + (size_t)r * 8u);
-    u32x4 v0 = {ca[0], ca[1], ca[2], ca[3]};
-    u32x4 v1 = {co[0], co[1], co[2], co[3]};
-    out[0] = v0;
-    out[1] = v1;
-    if (a.stats) {
-        double st[8];
-        assoc_stats(ca, co, st);
-        double *so = a.stats + (size_t)r * 8u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) so[j] = st[j];
-    }
+    if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
 // One step = UNROLL 1-KiB wave-loads per plane.  Never predicated: a lane past
