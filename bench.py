@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--snps", type=int, default=0, help="override SNPs per GPU (debug)")
     ap.add_argument("--chunks", type=int, default=4, help="scan/gather pipeline chunks when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurement of c2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
@@ -119,6 +120,29 @@ def cpu_baseline(table, n_samples, seconds):
     }
 
 
+def side_workload(name, steps, warmup):
+    """The same scan on another BASELINE.json shape (its own table), reported inside the JSON line
+    for information; not part of `value`."""
+    import torch
+    import libgwaspp_amd as gw
+    n, m, text = WORKLOADS[name]
+    with gw.GwTable(n, m) as t:
+        t.simulate(SEED, 0, 0)
+        t.simulate_phenotype(SEED)
+        buf = torch.empty(m * RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        base = buf.data_ptr()
+        for _ in range(warmup):
+            t.scan_case_control_device(0, m, base, base + m * 32, None)
+        t.synchronize()
+        t.timer_start(None)
+        for _ in range(steps):
+            t.scan_case_control_device(0, m, base, base + m * 32, None)
+        ms = t.timer_stop(None) / steps
+        gbps = m * (n / 4.0) / (ms * 1e-3) / 1e9
+        return {"workload": text, "ms_per_step": ms, "value": m / (ms * 1e-3), "unit": "SNPs/s",
+                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -174,6 +198,27 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
+    # the exchange step: per-SNP records to rank 0.  gather = grouped send/recv in RCCL, each
+    # slice over its own xGMI link; if this RCCL build refuses gather, fall back to all_gather
+    # (ring, per-link bound) rather than abort the run.
+    collective = {"name": "gather"}
+    allgather_out = None
+
+    def exchange(c):
+        nonlocal allgather_out
+        if collective["name"] == "gather":
+            try:
+                _, w = shard.gather_records(dist, bufs[c], rank, world, dst=0, async_op=True,
+                                            out=gathers[c] if rank == 0 else None)
+                return w
+            except (RuntimeError, NotImplementedError) as e:
+                if rank == 0:
+                    print(f"bench.py: dist.gather unavailable ({e}); using all_gather_into_tensor", file=sys.stderr)
+                collective["name"] = "all_gather"
+        if allgather_out is None:
+            allgather_out = [torch.empty(world * b.numel(), dtype=torch.uint8, device="cuda") for b in bufs]
+        return dist.all_gather_into_tensor(allgather_out[c], bufs[c], async_op=True)
+
     def step():
         works = []
         for c in range(n_chunks):
@@ -181,9 +226,7 @@ def main():
             base = bufs[c].data_ptr()
             table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
             if world > 1:
-                _, w = shard.gather_records(dist, bufs[c], rank, world, dst=0, async_op=True,
-                                            out=gathers[c] if rank == 0 else None)
-                works.append(w)
+                works.append(exchange(c))
         for w in works:
             w.wait()
 
@@ -208,11 +251,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    launches = args.steps * n_chunks
+    if world > 1:
+        # with the exchange in the loop the compute stream also waits for RCCL; time the scan
+        # kernel alone (same launches, no exchange) for the roofline figure
+        torch.cuda.synchronize()
+        table.timer_start(sptr)
+        for _ in range(args.steps):
+            for c in range(n_chunks):
+                rows = bounds[c + 1] - bounds[c]
+                base = bufs[c].data_ptr()
+                table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
+        kernel_ms_total = table.timer_stop(sptr)
+
     out = None
     if rank == 0:
         geo = table.geometry
         total_snps = n_snps * world
-        launches = args.steps * n_chunks
         kernel_ms = kernel_ms_total / max(1, launches)
         alg_bytes_per_launch = (n_snps / n_chunks) * (n_samples / 4.0)
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -246,7 +301,7 @@ def main():
                 "input": f"restated data/simulate_data.cpp (affy6 MAF spectrum, HWE, coin-flip phenotype), "
                          f"counter-based RNG seed {SEED:#x}, generated in HBM in {t_setup:.2f} s",
                 "sharding": "contiguous SNP ranges, one rank per GPU" if world > 1 else "single GPU",
-                "exchange": f"RCCL gather of {RECORD_BYTES} B/SNP to rank 0 in {n_chunks} chunks, "
+                "exchange": f"RCCL {collective['name']} of {RECORD_BYTES} B/SNP to rank 0 in {n_chunks} chunks, "
                             "overlapped with the scan" if world > 1 else "none",
                 "kernel_shape": shape, "stats_dtype": "f64",
             },
@@ -263,6 +318,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(table, n_samples, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and args.workload == "c3" and not args.snps and not args.no_extra:
+            out["extra_workloads"] = {"c2": side_workload("c2", args.steps, args.warmup)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -815,11 +815,9 @@ int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
     if (!t) return fail(GW_E_INVALID, "NULL table");
     int rc = use_device(t);
     if (rc) return rc;
-    const uint64_t n_units = t->geo.device_table_bytes / 16u;
-    if (n_units)
-        GW_HIP(gw::launch_stream_probe(t->tv.base, n_units, t->d_misc + 8, t->compute_units * 2,
-                                       pick_stream(t, hip_stream)));
-    if (bytes_read) *bytes_read = n_units * 16u;
+    GW_HIP(gw::launch_stream_probe(t->tv, t->d_misc + 8, t->compute_units, pick_stream(t, hip_stream)));
+    // bytes the probe loads: the sample-carrying units of both planes of every row
+    if (bytes_read) *bytes_read = t->tv.n_snps * 2ull * t->tv.units * 16ull;
     return GW_OK;
 }
 

@@ -75,9 +75,8 @@ hipError_t launch_simulate(const TableView &tv, uint64_t seed, uint64_t snp_glob
 hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl, uint32_t units,
                                      uint32_t n_samples, uint32_t *d_counts2, hipStream_t stream);
 
-// streaming-read probe over [base, base + n_units): returns a checksum in *d_sink
-hipError_t launch_stream_probe(const u32x4 *base, uint64_t n_units, uint32_t *d_sink,
-                               int grid_blocks, hipStream_t stream);
+// streaming-read probe: the scan's traversal of the table without the arithmetic
+hipError_t launch_stream_probe(const TableView &tv, uint32_t *d_sink, int grid_blocks, hipStream_t stream);
 
 // ---- pairwise path (gw_boost.hip) ------------------------------------------
 // marginal_information of one SNP (genotype/common_genotype.h:101-106)
