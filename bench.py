@@ -219,19 +219,30 @@ def main():
             allgather_out = [torch.empty(world * b.numel(), dtype=torch.uint8, device="cuda") for b in bufs]
         return dist.all_gather_into_tensor(allgather_out[c], bufs[c], async_op=True)
 
+    # chunk c's records travel while the following chunks (and the next step) are scanned; a chunk's
+    # buffer is only re-used once its previous exchange has completed (GPU-side stream wait)
+    pending = [None] * n_chunks
+
     def step():
-        works = []
         for c in range(n_chunks):
+            if pending[c] is not None:
+                pending[c].wait()
+                pending[c] = None
             rows = bounds[c + 1] - bounds[c]
             base = bufs[c].data_ptr()
             table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
             if world > 1:
-                works.append(exchange(c))
-        for w in works:
-            w.wait()
+                pending[c] = exchange(c)
+
+    def drain():
+        for c in range(n_chunks):
+            if pending[c] is not None:
+                pending[c].wait()
+                pending[c] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -240,6 +251,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()  # every step's records have reached rank 0 before the clock stops
     kernel_ms_total = table.timer_stop(sptr)  # HIP events on the launching stream; syncs on the stop event
     torch.cuda.synchronize()
     if world > 1:

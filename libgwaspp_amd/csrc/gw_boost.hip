@@ -140,10 +140,30 @@ __device__ __forceinline__ unsigned long long ordered(double v) {
 }
 }  // namespace
 
+// t1 = k/n and t1*log(t1) for every possible cell count k: the same expressions
+// the measure evaluates inline (so the table entries are bit-identical), done
+// once per table instead of 18 times per pair.
+__global__ void k_boost_tables(uint32_t n_entries, int n, double *frac, double *xlogx) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_entries) return;
+    const double t1 = (double)k / n;
+    frac[k] = t1;
+    xlogx[k] = k ? t1 * log(t1) : 0.0;
+}
+
+hipError_t launch_boost_tables(uint32_t n_entries, uint32_t n_individs, double *d_frac, double *d_xlogx,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(k_boost_tables, dim3((n_entries + 255u) / 256u), dim3(256), 0, stream, n_entries,
+                       (int)n_individs, d_frac, d_xlogx);
+    return hipGetLastError();
+}
+
 // computeBoost's measure for one pair from the two 3x3 tables
 // (epistasis_func.cpp:424-470); operation order as the oracle's gwo_boost_measure
 __device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const uint32_t (&co)[9],
-                                                const SnpMargin &m1, const SnpMargin &m2, int n) {
+                                                const SnpMargin &m1, const SnpMargin &m2, int n,
+                                                const double *__restrict__ frac,
+                                                const double *__restrict__ xlogx) {
     double tao = 0.0, im = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -155,13 +175,13 @@ __device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const u
             const double t3 = (pab) * (m2.pbc[4 + b]) * (m1.pca[4 + a]);
             tao += t2 + t3;
             if (x > 0) {
-                const double t1 = (double)x / n;
-                im += t1 * log(t1);
+                const double t1 = frac[x];  // (double)x / n
+                im += xlogx[x];             // t1 * log(t1)
                 if (t2 > 0) im += -t1 * log(t2);
             }
             if (y > 0) {
-                const double t1 = (double)y / n;
-                im += t1 * log(t1);
+                const double t1 = frac[y];
+                im += xlogx[y];
                 if (t3 > 0) im += -t1 * log(t3);
             }
         }
@@ -174,6 +194,7 @@ struct BoostArgs {
     uint64_t cc_stride_w;
     uint32_t wc, wt;
     const SnpMargin *mar;
+    const double *frac, *xlogx;  // k/n and (k/n) log(k/n), k = 0 .. n
     uint32_t a_begin, n_a, b_begin, n_b;
     int n_individs;
     double threshold;
@@ -301,7 +322,7 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
                         co[c] = cnt[1][2 * pi + pj][c];
                     }
                 }
-                measure = boost_measure(ca, co, m1, m2, a.n_individs);
+                measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
                 ++n_eval;
                 vmax = fmax(vmax, measure);
                 vmin = fmin(vmin, measure);
@@ -334,13 +355,14 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
 }
 
 hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
-                        const SnpMargin *d_mar, uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
+                        const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
+                        uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
-    a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar;
+    a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
     a.a_begin = a_begin; a.n_a = n_a; a.b_begin = b_begin; a.n_b = n_b;
     a.n_individs = (int)n_individs; a.threshold = threshold;
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;

@@ -69,6 +69,7 @@ struct gw_table {
     uint64_t cc_stride_w = 0;
     uint32_t wc = 0, wt = 0;
     gw::SnpMargin *d_mar = nullptr;
+    double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
     unsigned long long *d_tally = nullptr;
@@ -289,6 +290,8 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_misc) (void)hipFree(t->d_misc);
     if (t->d_cc) (void)hipFree(t->d_cc);
     if (t->d_mar) (void)hipFree(t->d_mar);
+    if (t->d_frac) (void)hipFree(t->d_frac);
+    if (t->d_xlogx) (void)hipFree(t->d_xlogx);
     if (t->d_tally) (void)hipFree(t->d_tally);
     if (t->ev_start) (void)hipEventDestroy(t->ev_start);
     if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
@@ -661,17 +664,16 @@ int ensure_selected(gw_table *t) {
     if (m) {
         std::vector<uint16_t> ctrl_only(t->h_ctrl);
         for (size_t b = 0; b < ctrl_only.size(); ++b) ctrl_only[b] = (uint16_t)(ctrl_only[b] & ~t->h_case[b]);
-        const std::vector<uint16_t> keep_ctrl(t->h_ctrl);
-        const uint32_t keep_nc = t->case_count, keep_nt = t->ctrl_count;
+        const std::vector<uint16_t> keep_case(t->h_case), keep_ctrl(t->h_ctrl);  // copies: set_case_control
+        const uint32_t keep_nc = t->case_count, keep_nt = t->ctrl_count;         // re-assigns the members
         const bool overlap = ctrl_only != keep_ctrl;
         if (overlap) {
-            rc = gw_table_set_case_control(t, t->h_case.data(), ctrl_only.data(), (uint32_t)ctrl_only.size(),
+            rc = gw_table_set_case_control(t, keep_case.data(), ctrl_only.data(), (uint32_t)ctrl_only.size(),
                                            (uint32_t)cases.size(), (uint32_t)ctrls.size());
             if (rc) return rc;
         }
         rc = gw_scan_case_control(t, 0, m, counts.data(), nullptr);
         if (overlap) {
-            const std::vector<uint16_t> keep_case(t->h_case);
             int rc2 = gw_table_set_case_control(t, keep_case.data(), keep_ctrl.data(), (uint32_t)keep_ctrl.size(),
                                                 keep_nc, keep_nt);
             if (!rc) rc = rc2;
@@ -682,6 +684,12 @@ int ensure_selected(gw_table *t) {
         GW_HIP(hipStreamSynchronize(t->stream));
     }
     t->sel_individs = (uint32_t)(cases.size() + ctrls.size());
+    if (t->d_frac) { GW_HIP(hipFree(t->d_frac)); t->d_frac = nullptr; }
+    if (t->d_xlogx) { GW_HIP(hipFree(t->d_xlogx)); t->d_xlogx = nullptr; }
+    GW_HIP(hipMalloc((void **)&t->d_frac, ((size_t)t->sel_individs + 1u) * sizeof(double)));
+    GW_HIP(hipMalloc((void **)&t->d_xlogx, ((size_t)t->sel_individs + 1u) * sizeof(double)));
+    GW_HIP(gw::launch_boost_tables(t->sel_individs + 1u, t->sel_individs, t->d_frac, t->d_xlogx, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
     t->any_missing = false;
     for (uint64_t r = 0; r < m && !t->any_missing; ++r)
         t->any_missing = counts[r * 8 + 3] != 0 || counts[r * 8 + 7] != 0;
@@ -717,7 +725,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0xFF, n_a * n_b * sizeof(double), t->stream);  // NaN
     }
     if (e == hipSuccess)
-        e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, (uint32_t)a_begin, (uint32_t)n_a,
+        e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
                              (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
                              max_hits, t->d_tally, d_dense, !t->any_missing, t->stream);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};

@@ -98,8 +98,11 @@ hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_
                           hipStream_t stream);
 // BOOST pre-screen of the SNP block pair [a_begin,+n_a) x [b_begin,+n_b), pairs i < j
 // d_tally: [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
+hipError_t launch_boost_tables(uint32_t n_entries, uint32_t n_individs, double *d_frac, double *d_xlogx,
+                               hipStream_t stream);
 hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
-                        const SnpMargin *d_mar, uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
+                        const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
+                        uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream);

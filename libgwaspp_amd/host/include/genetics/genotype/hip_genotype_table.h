@@ -18,6 +18,7 @@
 // Errors abort, like the reference's asserts.
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "genetics/genotype/geno_table.h"
@@ -68,6 +69,9 @@ public:
     // many pairs in one launch; out = n x 16 (and n x 16 for controls)
     void getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
                                          std::vector<uint> &cases, std::vector<uint> &ctrls);
+    // computeBoost's whole pre-screening loop (algorithms/epistasis_func.cpp:393-486) in one device
+    // pass: pairs (i, j, measure) with measure > threshold, in the reference's (i, j) visiting order
+    void boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing);
     void setScanWindow(uint rows) { window = rows ? rows : 1; invalidate(); }
     gw_table *handle() { return tbl; }
 

@@ -1,0 +1,191 @@
+// epistasis_func.cpp -- see algorithms/epistasis_func.h.
+#include "algorithms/epistasis_func.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "genetics/genotype/hip_genotype_table.h"
+
+namespace libgwaspp {
+namespace algorithms {
+
+void computeMargins(GenoTable &gt, int, marginal_information *&pMargins, int &nMarkerCount) {
+    nMarkerCount = gt.row_size();
+    delete[] pMargins;
+    pMargins = new marginal_information[nMarkerCount]();  // zeroed: entries of empty classes stay 0 (quirk Q6)
+    CaseControlGenotypeDistribution ccgd;
+    for (int i = 0; i < nMarkerCount; ++i) gt.getCaseControlGenotypeDistribution(i, ccgd, pMargins[i]);
+}
+
+double boostMeasureOnePair(const CONTIN_TABLE_T &ca, const CONTIN_TABLE_T &co, const marginal_information &m1,
+                           const marginal_information &m2, int nIndivids) {
+    double tao = 0.0, interMeasure = 0.0;
+    for (int a = 0; a < GT_COUNT; ++a)
+        for (int b = 0; b < GT_COUNT; ++b) {
+            const uint x = ca.contin[CONTIN_COLUMN_COUNT * a + b], y = co.contin[CONTIN_COLUMN_COUNT * a + b];
+            const double dPab = (double)(x + y) / (double)m2.margins.freq[b];
+            const double tmp2 = (dPab) * (m2.dPbc[b]) * (m1.dPca[a]);
+            const double tmp3 = (dPab) * (m2.dPbc[GENOTYPE_COUNT + b]) * (m1.dPca[GENOTYPE_COUNT + a]);
+            tao += tmp2 + tmp3;
+            if (x > 0) {
+                const double tmp1 = (double)x / nIndivids;
+                interMeasure += tmp1 * std::log(tmp1);
+                if (tmp2 > 0) interMeasure += -tmp1 * std::log(tmp2);
+            }
+            if (y > 0) {
+                const double tmp1 = (double)y / nIndivids;
+                interMeasure += tmp1 * std::log(tmp1);
+                if (tmp3 > 0) interMeasure += -tmp1 * std::log(tmp3);
+            }
+        }
+    return (interMeasure + std::log(tao)) * nIndivids * 2.0;
+}
+
+void gtestOnePair(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T &contin_co, const marginal_information &m1,
+                  const marginal_information &m2, uint nIndivids, double &interMeasure, double &z) {
+    const int J = GT_COUNT * GT_COUNT;
+    double mu[2][J], mu0[2][J];  // [0] cases, [1] controls
+    for (int i = 0; i < J; ++i) { mu[0][i] = mu[1][i] = 1.0; mu0[0][i] = mu0[1][i] = 0.0; }
+    // the reference sums |mu - mu0| eighteen times over the first element (:552-556)
+    double muError = 2.0 * J * std::fabs(mu[0][0] - mu0[0][0]);
+    while (muError > 0.001) {
+        std::memcpy(mu0, mu, sizeof mu);
+        double mu_ik[GT_BUFFER_SIZE] = {0}, mu_jk[GT_BUFFER_SIZE] = {0};
+        for (int a = 0; a < GT_COUNT; ++a)
+            for (int b = 0; b < GT_COUNT; ++b) {
+                const int i = GT_COUNT * a + b;
+                const uint tot = contin_ca.contin[CONTIN_COLUMN_COUNT * a + b] + contin_co.contin[CONTIN_COLUMN_COUNT * a + b];
+                const double mu_ij = mu[0][i] + mu[1][i];
+                if (mu_ij > 0) {
+                    mu[0][i] = mu[0][i] * (tot) / mu_ij;
+                    mu[1][i] = mu[1][i] * (tot) / mu_ij;
+                } else {
+                    mu[0][i] = 0;
+                    mu[1][i] = 0;
+                }
+                mu_ik[a] += mu[0][i];
+                mu_ik[GT_COUNT + a] += mu[1][i];
+                mu_jk[b] += mu[0][i];
+                mu_jk[GT_COUNT + b] += mu[1][i];
+            }
+        muError = 0.0;
+        for (int a = 0; a < GT_COUNT; ++a) {
+            const double tmp1 = mu_ik[a] > 0 ? m1.cases.freq[a] / mu_ik[a] : 0.0;
+            const double tmp2 = mu_ik[GT_COUNT + a] > 0 ? m1.controls.freq[a] / mu_ik[GT_COUNT + a] : 0.0;
+            for (int b = 0; b < GT_COUNT; ++b) {
+                const int i = GT_COUNT * a + b;
+                const double tmp3 = mu_jk[b] > 0 ? m2.cases.freq[b] / mu_jk[b] : 0.0;
+                const double tmp4 = mu_jk[GT_COUNT + b] > 0 ? m2.controls.freq[b] / mu_jk[GT_COUNT + b] : 0.0;
+                mu[0][i] = mu[0][i] * (tmp1)*tmp3;
+                mu[1][i] = mu[1][i] * (tmp2)*tmp4;
+                muError += std::fabs(mu[0][i] - mu0[0][i]);
+                muError += std::fabs(mu[1][i] - mu0[1][i]);
+            }
+        }
+    }
+    double tao = 0.0;
+    interMeasure = 0.0;
+    for (int a = 0; a < GT_COUNT; ++a)
+        for (int b = 0; b < GT_COUNT; ++b) {
+            const int i = GT_COUNT * a + b;
+            const uint x = contin_ca.contin[CONTIN_COLUMN_COUNT * a + b], y = contin_co.contin[CONTIN_COLUMN_COUNT * a + b];
+            double tmp1, tmp2;
+            if (x > 0) { tmp1 = (double)x / nIndivids; interMeasure += tmp1 * std::log(tmp1); } else tmp1 = 0.0;
+            if (mu[0][i] > 0) { tmp2 = mu[0][i] / nIndivids; interMeasure += -tmp1 * std::log(tmp2); tao += tmp2; }
+            if (y > 0) { tmp1 = (double)y / nIndivids; interMeasure += tmp1 * std::log(tmp1); } else tmp1 = 0.0;
+            if (mu[1][i] > 0) { tmp2 = mu[1][i] / nIndivids; interMeasure += -tmp1 * std::log(tmp2); tao += tmp2; }
+        }
+    interMeasure = (interMeasure + std::log(tao)) * nIndivids * 2.0;
+
+    // allele-level 2x2 per group and the difference of the log odds ratios (:686-701); uint arithmetic
+    uint aj[8];
+    const uint *t = contin_ca.contin;
+    for (int g = 0; g < 2; ++g, t = contin_co.contin) {
+        aj[4 * g + 0] = (t[0] << 2) + (t[1] << 1) + (t[4] << 1) + t[5];
+        aj[4 * g + 1] = (t[2] << 2) + (t[1] << 1) + (t[6] << 1) + t[5];
+        aj[4 * g + 2] = (t[8] << 2) + (t[9] << 1) + (t[4] << 1) + t[5];
+        aj[4 * g + 3] = (t[10] << 2) + (t[9] << 1) + (t[6] << 1) + t[5];
+    }
+    const double or_aff = std::log((double)(aj[0] * aj[3]) / (double)(aj[1] * aj[2]));
+    const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
+    const double or_unf = std::log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
+    const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
+    z = (or_aff - or_unf) / std::sqrt(v_aff + v_unf);
+}
+
+void computeGTest(GenoTable &gt, marginal_information *pMargins, uint nIndivids,
+                  std::vector<SNPInteractionPair> &passingThreshold, std::vector<double> &zval) {
+    CaseControlContingencyTable ccct;
+    for (SNPInteractionPair &p : passingThreshold) {
+        const uint i = p.first.first, j = p.first.second;
+        gt.getCaseControlContingencyTable(i, j, pMargins[i], pMargins[j], ccct);
+        double z;
+        gtestOnePair(*ccct.getCaseContingencyTable(), *ccct.getControlContingencyTable(), pMargins[i], pMargins[j],
+                     nIndivids, p.second, z);
+        zval.push_back(z);
+    }
+}
+
+void computeBoost(GeneticData *gd, std::ostream *out) {
+    CaseControlSet &ccs = *gd->getCaseControlSet();
+    const int nIndivids = (int)(ccs.getCaseCount() + ccs.getControlCount());
+    GenoTable &gt = *gd->getGenotypeTable();
+    gt.selectCaseControl(ccs);
+
+    marginal_information *pMargins = nullptr;
+    int nMarkerCount = 0;
+    computeMargins(gt, nIndivids, pMargins, nMarkerCount);
+    const double thresholdRecord = 30.0;  // :390
+    *out << "Pre-screening " << nMarkerCount << " SNP interactions" << std::endl;
+
+    std::vector<SNPInteractionPair> passingThreshold;
+    const auto t0 = std::chrono::steady_clock::now();
+    HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt);
+    if (hip) {
+        // the whole O(M^2) loop (:393-486) is one device pass
+        hip->boostScreen(thresholdRecord, passingThreshold);
+    } else {
+        CaseControlContingencyTable ccct;
+        for (int i = 0; i < nMarkerCount; ++i)
+            for (int j = i + 1; j < nMarkerCount; ++j) {
+                gt.getCaseControlContingencyTable(i, j, pMargins[i], pMargins[j], ccct);
+                const double m = boostMeasureOnePair(*ccct.getCaseContingencyTable(), *ccct.getControlContingencyTable(),
+                                                     pMargins[i], pMargins[j], nIndivids);
+                if (m > thresholdRecord) passingThreshold.push_back(SNPInteractionPair(SNPPair(i, j), m));
+            }
+    }
+    *out << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+    *out << "Located " << passingThreshold.size() << " potential interactions" << std::endl;
+    *out << "Performing deeper analysis of SNPs" << std::endl;
+
+    std::vector<double> zval;
+    computeGTest(gt, pMargins, (uint)nIndivids, passingThreshold, zval);
+    uint idx = 0;
+    char line[256];
+    for (size_t k = 0; k < passingThreshold.size(); ++k) {
+        if (passingThreshold[k].second > thresholdRecord) {
+            std::snprintf(line, sizeof line, "%7d\t%7d\t%7d\t%f\t%f\t%f\t%f", (int)idx++,
+                          (int)passingThreshold[k].first.first, (int)passingThreshold[k].first.second, 0.0, 0.0,
+                          passingThreshold[k].second, zval[k]);
+            *out << line << std::endl;
+        }
+    }
+    delete[] pMargins;
+}
+
+void ContingencyPerformance(GeneticData *gd, std::ostream *out) {
+    GenoTable &gt = *gd->getGenotypeTable();
+    const int m = gd->getGenotypedMarkersCount();
+    ContingencyTable ct;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < m; ++i)
+        for (int j = i + 1; j < m; ++j) gt.getContingencyTable(i, j, ct);
+    *out << "Contingencies " << m << ": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
+         << std::endl;
+}
+
+}  // namespace algorithms
+}  // namespace libgwaspp

@@ -285,5 +285,25 @@ void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t
                   "gw_pair_case_control_contingency");
 }
 
+void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing) {
+    if (!installed) std::abort();
+    passing.clear();
+    std::vector<gw_boost_hit> hits(1u << 16);
+    uint64_t n_hits = 0;
+    for (;;) {
+        die_unless_ok(gw_boost_screen(tbl, 0, (uint64_t)max_row, 0, (uint64_t)max_row, threshold, hits.data(), hits.size(),
+                                      &n_hits, nullptr, nullptr, nullptr),
+                      "gw_boost_screen");
+        if (n_hits <= hits.size()) break;
+        hits.resize(n_hits);  // the list was capped: run again with room for all of it
+    }
+    hits.resize(n_hits);
+    std::sort(hits.begin(), hits.end(), [](const gw_boost_hit &a, const gw_boost_hit &b) {
+        return a.snp_a != b.snp_a ? a.snp_a < b.snp_a : a.snp_b < b.snp_b;
+    });
+    for (const gw_boost_hit &h : hits)
+        passing.push_back(std::make_pair(std::make_pair((uint)h.snp_a, (uint)h.snp_b), h.measure));
+}
+
 }  // namespace genetics
 }  // namespace libgwaspp

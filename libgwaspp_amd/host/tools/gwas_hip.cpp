@@ -11,6 +11,8 @@
 //   --valid-geno           every call decoded back (validate_func.cpp:31-55)
 //   --contin-debug         4x4 table of every SNP pair (epistasis_func.cpp:84-103)
 //   --epi-debug            case/control tables of every pair, all three getters
+//   --test-boost-epi       computeBoost: KSA pre-screen of all pairs + exact G test on the hits
+//   --contin-perform       ContingencyPerformance timing harness
 //   --assoc                counts + MAF/HWE/chi-square of every SNP
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +21,7 @@
 #include <iostream>
 #include <string>
 
+#include "algorithms/epistasis_func.h"
 #include "algorithms/maf_func.h"
 #include "genetics/genotype/hip_genotype_table.h"
 #include "genetics/individual/tplink_files.h"
@@ -29,7 +32,7 @@ using namespace libgwaspp::algorithms;
 static void usage() {
     std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] "
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
-                 "--valid-geno|--contin-debug|--epi-debug|--assoc\n";
+                 "--valid-geno|--contin-debug|--epi-debug|--test-boost-epi|--contin-perform|--assoc\n";
     std::exit(2);
 }
 
@@ -111,6 +114,10 @@ int main(int argc, char **argv) {
                     print_table(*out, *t->getControlContingencyTable());
                 }
             }
+    } else if (mode == "--test-boost-epi") {
+        computeBoost(&gd, out);
+    } else if (mode == "--contin-perform") {
+        ContingencyPerformance(&gd, out);
     } else if (mode == "--assoc") {
         HipGenotypeTable &ht = static_cast<HipGenotypeTable &>(gt);
         CaseControlSet &ccs = *gd.getCaseControlSet();

@@ -847,6 +847,78 @@ void gwo_boost_all_pairs(const uint16_t *table, uint32_t n_snps, const gwo_geom 
     free(mar);
 }
 
+/* computeGTest, algorithms/epistasis_func.cpp:508-704, for one pair */
+void gwo_gtest(const uint32_t ca_tab[16], const uint32_t co_tab[16], const gwo_marginal *m1,
+               const gwo_marginal *m2, uint32_t n_individs, double *measure, double *zval) {
+    const uint32_t f1c[3] = {m1->cases.aa, m1->cases.ab, m1->cases.bb};
+    const uint32_t f1t[3] = {m1->controls.aa, m1->controls.ab, m1->controls.bb};
+    const uint32_t f2c[3] = {m2->cases.aa, m2->cases.ab, m2->cases.bb};
+    const uint32_t f2t[3] = {m2->controls.aa, m2->controls.ab, m2->controls.bb};
+    double mu_ca[9], mu_co[9], old_ca[9], old_co[9];
+    for (int i = 0; i < 9; ++i) { mu_ca[i] = mu_co[i] = 1.0; old_ca[i] = old_co[i] = 0.0; }
+    double err = 18.0 * fabs(mu_ca[0] - old_ca[0]); /* :552-556 */
+    while (err > 0.001) {
+        memcpy(old_ca, mu_ca, sizeof mu_ca);
+        memcpy(old_co, mu_co, sizeof mu_co);
+        double ik[6] = {0, 0, 0, 0, 0, 0}, jk[6] = {0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) { /* :571-598 */
+                const int i = 3 * a + b;
+                const uint32_t tot = ca_tab[4 * a + b] + co_tab[4 * a + b];
+                const double mij = mu_ca[i] + mu_co[i];
+                if (mij > 0) {
+                    mu_ca[i] = mu_ca[i] * (tot) / mij;
+                    mu_co[i] = mu_co[i] * (tot) / mij;
+                } else {
+                    mu_ca[i] = 0;
+                    mu_co[i] = 0;
+                }
+                ik[a] += mu_ca[i]; ik[3 + a] += mu_co[i];
+                jk[b] += mu_ca[i]; jk[3 + b] += mu_co[i];
+            }
+        err = 0.0;
+        for (int a = 0; a < 3; ++a) { /* :611-645 */
+            const double t1 = ik[a] > 0 ? f1c[a] / ik[a] : 0.0;
+            const double t2 = ik[3 + a] > 0 ? f1t[a] / ik[3 + a] : 0.0;
+            for (int b = 0; b < 3; ++b) {
+                const int i = 3 * a + b;
+                const double t3 = jk[b] > 0 ? f2c[b] / jk[b] : 0.0;
+                const double t4 = jk[3 + b] > 0 ? f2t[b] / jk[3 + b] : 0.0;
+                mu_ca[i] = mu_ca[i] * (t1)*t3;
+                mu_co[i] = mu_co[i] * (t2)*t4;
+                err += fabs(mu_ca[i] - old_ca[i]);
+                err += fabs(mu_co[i] - old_co[i]);
+            }
+        }
+    }
+    double tao = 0.0, im = 0.0; /* :648-683 */
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const int i = 3 * a + b;
+            const uint32_t ca = ca_tab[4 * a + b], co = co_tab[4 * a + b];
+            double t1, t2;
+            if (ca > 0) { t1 = (double)ca / n_individs; im += t1 * log(t1); } else t1 = 0.0;
+            if (mu_ca[i] > 0) { t2 = mu_ca[i] / n_individs; im += -t1 * log(t2); tao += t2; }
+            if (co > 0) { t1 = (double)co / n_individs; im += t1 * log(t1); } else t1 = 0.0;
+            if (mu_co[i] > 0) { t2 = mu_co[i] / n_individs; im += -t1 * log(t2); tao += t2; }
+        }
+    *measure = (im + log(tao)) * n_individs * 2.0;
+    /* allelic joint distribution and the odds-ratio z value, :686-701 (uint arithmetic) */
+    uint32_t aj[8];
+    const uint32_t *t = ca_tab;
+    for (int g = 0; g < 2; ++g, t = co_tab) {
+        aj[4 * g + 0] = (t[0] << 2) + (t[1] << 1) + (t[4] << 1) + t[5];
+        aj[4 * g + 1] = (t[2] << 2) + (t[1] << 1) + (t[6] << 1) + t[5];
+        aj[4 * g + 2] = (t[8] << 2) + (t[9] << 1) + (t[4] << 1) + t[5];
+        aj[4 * g + 3] = (t[10] << 2) + (t[9] << 1) + (t[6] << 1) + t[5];
+    }
+    const double or_aff = log((double)(aj[0] * aj[3]) / (double)(aj[1] * aj[2]));
+    const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
+    const double or_unf = log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
+    const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
+    *zval = (or_aff - or_unf) / sqrt(v_aff + v_unf);
+}
+
 /* ------------------------------------------------------------------------ */
 /* pairwise LLR, src/test/pairwise.c:50-133                                  */
 /* ------------------------------------------------------------------------ */

@@ -212,6 +212,15 @@ void gwo_boost_all_pairs(const uint16_t *table, uint32_t n_snps, const gwo_geom 
                          const uint16_t *case_stream, const uint16_t *ctrl_stream,
                          uint32_t case_count, uint32_t ctrl_count, double *measures);
 
+/* Stage 2 of computeBoost on one pair that passed the screen: computeGTest
+ * (algorithms/epistasis_func.cpp:508-704) -- iterative proportional fitting of
+ * the no-three-way-interaction model, the exact measure (:650-683) and the
+ * allelic odds-ratio z value (:686-701).  Parity unpinned (the reference holds
+ * no expected values); restated with its quirks: the initial error is 18
+ * (:552-556 never advances its pointers), uint32 products in the odds ratios. */
+void gwo_gtest(const uint32_t case_tab[16], const uint32_t ctrl_tab[16], const gwo_marginal *m1,
+               const gwo_marginal *m2, uint32_t n_individs, double *measure, double *zval);
+
 /* ---- pairwise LLR known-answer test (src/test/pairwise.c:50-133; NEXT row) ---- */
 double gwo_pairwise_llr(const uint32_t case_tab[9], const uint32_t ctrl_tab[9]);
 

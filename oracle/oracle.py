@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         L.gwo_boost_measure.argtypes = [u32p, u32p, C.POINTER(Marginal), C.POINTER(Marginal), C.c_uint32]
         L.gwo_boost_measure.restype = C.c_double
         L.gwo_boost_all_pairs.argtypes = [u16p, C.c_uint32, gp, u16p, u16p, C.c_uint32, C.c_uint32, f64p]
+        L.gwo_gtest.argtypes = [u32p, u32p, C.POINTER(Marginal), C.POINTER(Marginal), C.c_uint32, f64p, f64p]
         L.gwo_pairwise_llr.argtypes = [u32p, u32p]
         L.gwo_pairwise_llr.restype = C.c_double
         _lib = L
@@ -293,6 +294,15 @@ def boost_all_pairs(table, g, case_stream, ctrl_stream, case_count, ctrl_count) 
     lib().gwo_boost_all_pairs(_p16(table), m, C.byref(g), _p16(case_stream), _p16(ctrl_stream),
                               case_count, ctrl_count, _pf64(out))
     return out
+
+
+def gtest(case16, ctrl16, m1: "Marginal", m2: "Marginal", n_individs: int):
+    """-> (exact measure after IPF, allelic odds-ratio z)"""
+    a = np.ascontiguousarray(np.asarray(case16, dtype=np.uint32).reshape(16))
+    b = np.ascontiguousarray(np.asarray(ctrl16, dtype=np.uint32).reshape(16))
+    me, z = C.c_double(), C.c_double()
+    lib().gwo_gtest(_p32(a), _p32(b), C.byref(m1), C.byref(m2), n_individs, C.byref(me), C.byref(z))
+    return me.value, z.value
 
 
 def pairwise_llr(case_tab, ctrl_tab) -> float:

@@ -4,12 +4,14 @@
 //   host_cpu_probe ccs <n> <case idx,...> <ctrl idx,...>
 //   host_cpu_probe marginal <8 counts>
 //   host_cpu_probe maf <4 counts>
+//   host_cpu_probe gtest <9 case cells> <9 control cells>   (3x3 tables, no missing calls)
 #include <cstdio>
 #include <cstdlib>
 #include <set>
 #include <sstream>
 #include <string>
 
+#include "algorithms/epistasis_func.h"
 #include "algorithms/maf_func.h"
 #include "genetics/analyzable/case_control_set.h"
 #include "genetics/genotype/common_genotype_func.h"
@@ -62,6 +64,30 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 8; ++i) std::printf(" %.17g", m.dPbc[i]);
         for (int i = 0; i < 8; ++i) std::printf(" %.17g", m.dPca[i]);
         std::printf("\n");
+        return 0;
+    }
+    if (mode == "gtest" && argc == 20) {
+        CONTIN_TABLE_T ca, co;
+        ResetContingencyTable(ca);
+        ResetContingencyTable(co);
+        frequency_table f1c, f1t, f2c, f2t;
+        ResetFrequencyTable(f1c); ResetFrequencyTable(f1t); ResetFrequencyTable(f2c); ResetFrequencyTable(f2t);
+        uint n = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const uint x = std::atoi(argv[2 + 3 * a + b]), y = std::atoi(argv[11 + 3 * a + b]);
+                ca.contin[4 * a + b] = x;
+                co.contin[4 * a + b] = y;
+                f1c.freq[a] += x; f2c.freq[b] += x;
+                f1t.freq[a] += y; f2t.freq[b] += y;
+                n += x + y;
+            }
+        marginal_information m1 = marginal_information(), m2 = marginal_information();
+        computeMarginalInformation(f1c, f1t, n, m1);
+        computeMarginalInformation(f2c, f2t, n, m2);
+        double measure, z;
+        libgwaspp::algorithms::gtestOnePair(ca, co, m1, m2, n, measure, z);
+        std::printf("%.17g %.17g %.17g\n", libgwaspp::algorithms::boostMeasureOnePair(ca, co, m1, m2, (int)n), measure, z);
         return 0;
     }
     if (mode == "maf" && argc == 6) {

@@ -134,3 +134,63 @@ def test_assoc_statistics(oracle):
     for r, t in enumerate(rows):
         assert [int(v) for v in t[:8]] == [int(v) for v in wc[r]]
         np.testing.assert_allclose([float(v) for v in t[8:]], ws[r], rtol=1e-10, atol=1e-12)
+
+
+def test_compute_boost_report(oracle, tmp_path):
+    """computeBoost through the harness (--test-boost-epi): KSA pre-screen of all pairs on the
+    GPU, exact G test on the hits, the reference's report lines -- against the oracle's
+    restatement of the same pipeline (epistasis_func.cpp:349-506, 508-704)."""
+    import ctypes as C
+    n, m = 3000, 40
+    rng = np.random.default_rng(21)
+    status = rng.integers(0, 2, size=n)
+    q = rng.uniform(0.1, 0.5, size=(m, 1))
+    a = (rng.random((m, n)) < q).astype(np.uint8) + (rng.random((m, n)) < q).astype(np.uint8)  # minor-allele count
+    # two planted interactions: in cases the second SNP copies the first
+    for i, j in ((3, 17), (20, 31)):
+        copy = (status == 1) & (rng.random(n) < 0.7)
+        a[j, copy] = a[i, copy]
+    a[:, 0], a[:, 1], a[:, 2] = 0, 1, 2     # every row starts AA, AC, CC: code space == allele space
+    sym = np.array(["A A", "A C", "C C"])
+    with open(tmp_path / "d.tped", "w") as f:
+        for r in range(m):
+            f.write(f"0 rs{r} 0 {r} " + " ".join(sym[a[r]]) + "\n")
+    with open(tmp_path / "d.tfam", "w") as f:
+        for s in range(n):
+            f.write(f"Fam_{s} Ind_{s} Pat_{s} Mat_{s} x {status[s]}\n")
+    cmd = [CLI, "-g", str(tmp_path / "d.tped"), "-p", str(tmp_path / "d.tfam"), "--test-boost-epi"]
+    text = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    rows = [ln.split("\t") for ln in text.splitlines() if ln.count("\t") == 6]
+    located = [ln for ln in text.splitlines() if ln.startswith("Located ")]
+
+    # the oracle's pipeline
+    ts = oracle.pack_codes(a + 1, "stream")
+    gs = oracle.geometry_stream(n)
+    _, cs, nc = oracle.ccs_masks(np.flatnonzero(status == 1), n)
+    _, ct, nt = oracle.ccs_masks(np.flatnonzero(status == 0), n)
+    flat = oracle.boost_all_pairs(ts, gs, cs, ct, nc, nt)
+    pad = gs.words * 64
+    mar = []
+    for r in range(m):
+        ca, co = oracle.stream_cc_dist(ts[r], gs, cs, ct, nc, nt)
+        mar.append(oracle.marginal_information(ca, co, n))
+    want, k, passed = [], 0, 0
+    for i in range(m):
+        for j in range(i + 1, m):
+            if flat[k] > 30.0:
+                passed += 1
+                c16, t16 = oracle.stream_cc_contingency(ts[i], ts[j], gs, cs, ct)
+                c16[15] -= pad - nc
+                t16[15] -= pad - nt
+                measure, z = oracle.gtest(c16, t16, mar[i], mar[j], n)
+                if measure > 30.0:
+                    want.append((i, j, measure, z))
+            k += 1
+    assert located == [f"Located {passed} potential interactions"]
+    assert len(rows) == len(want) >= 2
+    assert {(3, 17), (20, 31)} <= {(w[0], w[1]) for w in want}
+    for idx, (got, w) in enumerate(zip(rows, want)):
+        assert [int(got[0]), int(got[1]), int(got[2])] == [idx, w[0], w[1]]
+        assert float(got[3]) == 0.0 and float(got[4]) == 0.0
+        assert float(got[5]) == pytest.approx(w[2], abs=2e-6)
+        assert float(got[6]) == pytest.approx(w[3], abs=2e-6)

@@ -16,11 +16,13 @@ PROBE = os.path.join(BUILD, "host_cpu_probe")
 @pytest.fixture(scope="module")
 def probe():
     os.makedirs(BUILD, exist_ok=True)
-    srcs = [os.path.join(ROOT, "tests", "cpp", "host_cpu_probe.cpp"),
-            os.path.join(HOST, "src", "case_control_set.cpp"),
-            os.path.join(HOST, "src", "common_genotype_func.cpp")]
-    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(HOST, "include"), "-o", PROBE] + srcs,
-                   check=True)
+    # the probe links the product's host library (its GPU-free classes and functions are what is probed)
+    pkg = os.path.join(ROOT, "libgwaspp_amd")
+    subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-s"], check=True)
+    subprocess.run(["make", "-C", HOST, "-s"], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(ROOT, "include"),
+                    "-o", PROBE, os.path.join(ROOT, "tests", "cpp", "host_cpu_probe.cpp"),
+                    "-L" + pkg, "-lgwaspp_hip", "-lgwscan", "-Wl,-rpath," + pkg], check=True)
 
     def run(*args):
         r = subprocess.run([PROBE] + [str(a) for a in args], check=True, capture_output=True, text=True)
@@ -69,3 +71,27 @@ def test_minor_allele_frequency_mirror(oracle, probe):
     for ft in [(10, 20, 70, 5), (70, 20, 10, 0), (25, 0, 75, 0), (1, 1, 1, 1)]:
         tot, maf = (float(v) for v in probe("maf", *ft)[0].split())
         assert (tot, maf) == oracle.minor_allele_frequency(ft)
+
+
+def test_boost_measure_and_gtest_mirror(oracle, probe):
+    """computeBoost's measure and computeGTest (epistasis_func.cpp:424-470, 508-704) in the C++
+    mirror vs the oracle's restatement, incl. the pairwise.c known-answer tables."""
+    from test_oracle_arith import PAIRWISE_KAT
+    rng = np.random.default_rng(11)
+    tables = [(np.array(cs), np.array(ct), llr) for _, cs, ct, llr in PAIRWISE_KAT]
+    for _ in range(20):
+        tables.append((rng.integers(1, 400, size=(3, 3)), rng.integers(1, 400, size=(3, 3)), None))
+    tables.append((np.array([[5, 0, 3], [0, 0, 0], [2, 9, 1]]), np.array([[1, 0, 0], [0, 0, 0], [7, 2, 2]]), None))
+    for cs, ct, llr in tables:
+        got = [float(v) for v in probe("gtest", *cs.reshape(-1), *ct.reshape(-1))[0].split()]
+        c16, t16 = np.zeros((4, 4), np.uint32), np.zeros((4, 4), np.uint32)
+        c16[:3, :3], t16[:3, :3] = cs, ct
+        n = int(cs.sum() + ct.sum())
+        m1 = oracle.marginal_information(tuple(int(v) for v in cs.sum(axis=1)) + (0,),
+                                         tuple(int(v) for v in ct.sum(axis=1)) + (0,), n)
+        m2 = oracle.marginal_information(tuple(int(v) for v in cs.sum(axis=0)) + (0,),
+                                         tuple(int(v) for v in ct.sum(axis=0)) + (0,), n)
+        want = (oracle.boost_measure(c16, t16, m1, m2, n),) + oracle.gtest(c16, t16, m1, m2, n)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)
+        if llr is not None:
+            assert got[0] == pytest.approx(llr, rel=1e-10)
