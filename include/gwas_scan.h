@@ -242,6 +242,10 @@ typedef enum gw_option {
     GW_OPT_BLOCKS_PER_CU = 3,/* persistent workgroups per CU (0 = auto)          */
     GW_OPT_NONTEMPORAL = 4,  /* 1: nt loads for the genotype stream (default)     */
     GW_OPT_BLOCK_THREADS = 5,/* threads per workgroup: 256, 512, 1024 (0 = auto) */
+    GW_OPT_COMPLEMENT = 7,   /* when the control mask is exactly the complement of the case mask the scan
+                                can stage one mask in LDS and take controls = all - cases: 0 never,
+                                1 (default) only where two masks do not fit the LDS (650 k < N <= 1.3 M),
+                                2 whenever possible; get returns whether the current masks/shape use it */
     GW_OPT_PIPELINE = 6      /* 1: next step's loads issued before the current step is consumed,
                                 across row boundaries; 0: row-at-a-time kernel (default) */
 } gw_option;

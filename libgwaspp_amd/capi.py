@@ -23,7 +23,7 @@ LAYOUT_BLOCK = 3
 N_COUNTS = 8
 N_STATS = 8
 
-OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS, OPT_PIPELINE = 1, 2, 3, 4, 5, 6
+OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS, OPT_PIPELINE, OPT_COMPLEMENT = 1, 2, 3, 4, 5, 6, 7
 
 
 class GwError(RuntimeError):

@@ -31,6 +31,7 @@ struct ScanShape {
     int mask_in_lds;    // stage masks in LDS
     int nontemporal;    // nt loads on the genotype stream
     int block_threads;  // 256/512/1024
+    int complement;     // 1: control mask == ~case mask: single-mask kernel (k_scan_cc_compl)
     int pipeline;       // 1: continuous-stream kernel (k_scan_cc_pipe), 0: row-at-a-time (k_scan_cc)
     int grid_blocks;    // persistent workgroups
     size_t lds_bytes;

@@ -252,6 +252,83 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
+// Complementary-mask form of the scan, for the usual phenotype where every
+// sample is either a case or a control (control mask == ~case mask over the
+// N samples; data/simulate_data.cpp:219-235 produces exactly that): only the
+// case mask is staged in LDS (N/8 bytes -- fits up to N ~ 1.3 M), the counts of
+// ALL samples are taken without a mask and controls = all - cases.  Same six
+// integers per row, 4 AND + 6 popcount per word instead of 6 + 6.
+__device__ __forceinline__ void acc_unit_compl(const u32x4 a, const u32x4 b, const u32x4 mc, uint32_t (&c)[6]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = a[k] & mc[k], y = b[k] & mc[k];
+        c[0] += __popc(x);
+        c[1] += __popc(y);
+        c[2] += __popc(x & y);
+        c[3] += __popc(a[k]);
+        c[4] += __popc(b[k]);
+        c[5] += __popc(a[k] & b[k]);
+    }
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(1024) k_scan_cc_compl(ScanArgs a) {
+    extern __shared__ u32x4 lds_masks[];  // [units]: the case mask
+    const uint32_t units = a.units;
+    for (uint32_t u = threadIdx.x; u < units; u += blockDim.x) lds_masks[u] = a.case_mask[u];
+    __syncthreads();
+    const u32x4 *mcase = lds_masks;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    constexpr uint32_t STEP = 64u * UNROLL;
+    const uint32_t full = (units / STEP) * STEP;
+
+    uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t my_row = 0xFFFFFFFFu, slot = 0;
+    for (uint32_t r = gwave; r < a.n_rows; r += total_waves) {
+        const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
+        const u32x4 *p1 = p0 + a.plane_stride_u;
+        uint32_t c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t base = 0; base < full; base += STEP) {
+            u32x4 A[UNROLL], B[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                A[k] = ld_stream<true>(p0 + base + 64u * k + lane);
+                B[k] = ld_stream<true>(p1 + base + 64u * k + lane);
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const u32x4 mc = mcase[base + 64u * k + lane];
+                if (k & 1) acc_unit_compl(A[k], B[k], mc, c1);
+                else acc_unit_compl(A[k], B[k], mc, c0);
+            }
+        }
+        for (uint32_t u = full + lane; u < units; u += 64u) {
+            const u32x4 A = ld_stream<true>(p0 + u), B = ld_stream<true>(p1 + u);
+            acc_unit_compl(A, B, mcase[u], c0);
+        }
+        const bool park = lane == slot;
+        uint32_t tot[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tot[j] = wave_sum_dpp(c0[j] + c1[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            mine[j] = park ? tot[j] : mine[j];                    // cases
+            mine[3 + j] = park ? tot[3 + j] - tot[j] : mine[3 + j];  // controls = all - cases
+        }
+        my_row = park ? r : my_row;
+        if (++slot == 64u) {
+            finish_row(a, my_row, mine);
+            my_row = 0xFFFFFFFFu;
+            slot = 0;
+        }
+    }
+    if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
+}
+
 // One step = UNROLL 1-KiB wave-loads per plane.  Never predicated: a lane past
 // the end of the row re-reads the row's last unit (its mask words are zero), so
 // that the compiler can count the loads in flight and wait for exactly the
@@ -403,6 +480,15 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
     a.ctrl_count = ctrl_count;
     a.counts = d_counts;
     a.stats = d_stats;
+    if (sh.complement) {
+        switch (sh.unroll) {
+        case 1: hipLaunchKernelGGL((k_scan_cc_compl<1>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;
+        case 4: hipLaunchKernelGGL((k_scan_cc_compl<4>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;
+        case 8: hipLaunchKernelGGL((k_scan_cc_compl<8>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;
+        default: hipLaunchKernelGGL((k_scan_cc_compl<2>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;
+        }
+        return hipGetLastError();
+    }
     switch (sh.unroll) {
     case 1: return launch_scan_u<1>(a, sh, stream);
     case 2: return launch_scan_u<2>(a, sh, stream);
@@ -429,6 +515,11 @@ static hipError_t prepare_u(size_t bytes) {
 
 hipError_t prepare_scan_kernels(size_t max_lds_bytes) {
     hipError_t e;
+    const int b = (int)max_lds_bytes;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<1>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<2>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     if ((e = prepare_u<1>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = prepare_u<2>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = prepare_u<4>(max_lds_bytes)) != hipSuccess) return e;

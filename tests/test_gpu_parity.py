@@ -283,3 +283,44 @@ def test_simulator_equals_oracle(oracle, n, missing):
         wc, ws = oracle.scan_stream_cc(want, g, ocs, oct_, onc, ont)
         assert np.array_equal(counts, wc)
         _assert_stats(stats, ws)
+
+
+@pytest.mark.parametrize("n,m", [(1, 3), (64, 20), (129, 40), (5000, 300), (70_001, 200)])
+def test_complementary_mask_kernel(oracle, n, m):
+    """When the control mask is exactly the complement of the case mask the scan uses one mask
+    and controls = all - cases (k_scan_cc_compl); same records as the two-mask kernel."""
+    rng = np.random.default_rng(n)
+    codes = _random_codes(rng, m, n, p_missing=0.05)
+    ts = oracle.pack_codes(codes, "stream")
+    gs = oracle.geometry_stream(n)
+    is_case = rng.random(n) < 0.4
+    _, cs, nc = oracle.ccs_masks(np.flatnonzero(is_case), n)
+    _, ct, nt = oracle.ccs_masks(np.flatnonzero(~is_case), n)
+    want_counts, want_stats = oracle.scan_stream_cc(ts, gs, cs, ct, nc, nt)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        assert t.get_option(capi.OPT_COMPLEMENT) == 0   # auto: both masks fit the LDS here
+        t.set_option(capi.OPT_COMPLEMENT, 2)
+        assert t.get_option(capi.OPT_COMPLEMENT) == 1
+        for unroll in (0, 1, 2, 4, 8):
+            t.set_option(capi.OPT_UNROLL, unroll)
+            counts, stats = t.scan_case_control()
+            assert np.array_equal(counts, want_counts)
+            _assert_stats(stats, want_stats)
+        t.set_option(capi.OPT_COMPLEMENT, 0)
+        assert t.get_option(capi.OPT_COMPLEMENT) == 0
+        c2, s2 = t.scan_case_control()
+        assert np.array_equal(c2, want_counts) and np.array_equal(s2, stats)
+        t.set_option(capi.OPT_COMPLEMENT, 2)
+        # one sample in neither group: no longer complementary -> two-mask kernel, same API
+        if n > 2:
+            ct2 = ct.copy()
+            drop = int(np.flatnonzero(~is_case)[0])
+            ct2[drop >> 4] &= np.uint16(~(1 << (drop & 15)) & 0xFFFF)
+            t.set_case_control(cs, ct2, nc, nt - 1)
+            assert t.get_option(capi.OPT_COMPLEMENT) == 0
+            wc, ws = oracle.scan_stream_cc(ts, gs, cs, ct2, nc, nt - 1)
+            counts, stats = t.scan_case_control()
+            assert np.array_equal(counts, wc)
+            _assert_stats(stats, ws)

@@ -27,7 +27,8 @@ ap.add_argument("--threads", default="256,512,1024")
 ap.add_argument("--per-cu", default="0")
 ap.add_argument("--lds", default="1")
 ap.add_argument("--nt", default="1")
-ap.add_argument("--pipe", default="1")
+ap.add_argument("--pipe", default="0")
+ap.add_argument("--compl", default="1", help="0 never, 1 auto, 2 whenever possible")
 ap.add_argument("--stats", type=int, default=1)
 args = ap.parse_args()
 
@@ -43,12 +44,13 @@ base = buf.data_ptr()
 alg = m * (n / 4.0)
 
 lst = lambda s: [int(x) for x in s.split(",")]
-combos = list(itertools.product(lst(args.unroll), lst(args.threads), lst(args.per_cu), lst(args.lds), lst(args.nt), lst(args.pipe)))
+combos = list(itertools.product(lst(args.unroll), lst(args.threads), lst(args.per_cu), lst(args.lds), lst(args.nt), lst(args.pipe), lst(args.compl)))
 res = {c: [] for c in combos}
 for rnd in range(args.rounds):
     for c in combos:
-        u, th, pc, lds, nt, pipe = c
+        u, th, pc, lds, nt, pipe, cm = c
         t.set_option(capi.OPT_PIPELINE, pipe)
+        t.set_option(capi.OPT_COMPLEMENT, cm)
         t.set_option(capi.OPT_UNROLL, u)
         t.set_option(capi.OPT_BLOCK_THREADS, th)
         t.set_option(capi.OPT_BLOCKS_PER_CU, pc)
@@ -66,8 +68,8 @@ for _ in range(3):
     nb = t.stream_read_probe(None)
     probe.append(nb / (t.timer_stop(None) * 1e-3) / 1e9)
 print(f"workload {args.workload}: {n} x {m}, algorithmic {alg/1e9:.2f} GB/launch, probe {max(probe):.0f} GB/s")
-print("unroll thr perCU lds nt pipe | median ms | min ms | GB/s(min) | %peak")
+print("unroll thr perCU lds nt pipe compl | median ms | min ms | GB/s(min) | %peak")
 for c, v in sorted(res.items(), key=lambda kv: min(kv[1])):
     med, mn = float(np.median(v)), min(v)
-    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f}")
+    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f}")
 t.close()
