@@ -48,3 +48,24 @@ def gather_ragged(dist, local, rank: int, world: int, sizes: list[int], dst: int
     if rank != dst:
         return None
     return [t[:s] for t, s in zip(out, sizes)]
+
+
+def pair_row_blocks(n_snps: int, rank: int, world: int, block: int = 1024) -> list[tuple[int, int]]:
+    """Sharding of the SNP-pair space {(i, j): i < j} for the BOOST pre-screen: the rows i are cut
+    into blocks of `block` SNPs, dealt over the ranks in snake order (0..W-1, W-1..0, ...: row
+    block k holds about block * (n_snps - k*block) pairs, so the snake balances the triangle to
+    well under 1 %); the rank screens
+    [a, a+n) x [a, n_snps) for each of its blocks.  Every rank holds the whole table (the reference's
+    computeBoost needs every row against every other; 100 k SNPs x 10 k samples is 250 MB).
+    Returns [(a_begin, n_a), ...]."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside the world")
+    out = []
+    n_blocks = (n_snps + block - 1) // block
+    for k in range(n_blocks):
+        rnd, pos = divmod(k, world)
+        owner = pos if rnd % 2 == 0 else world - 1 - pos
+        if owner == rank:
+            a = k * block
+            out.append((a, min(block, n_snps - a)))
+    return out

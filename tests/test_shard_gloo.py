@@ -80,6 +80,23 @@ def test_snp_range_partition():
     assert shard.chunk_bounds(2, 4) == [0, 1, 2]
 
 
+def test_pair_row_blocks_cover_the_triangle_once():
+    from libgwaspp_amd import shard
+    for n in (1, 7, 1000, 4097, 100_000):
+        for world in (1, 2, 3, 8):
+            seen = np.zeros(n, dtype=np.int32)
+            pairs = []
+            for r in range(world):
+                blocks = shard.pair_row_blocks(n, r, world, block=512)
+                for a, na in blocks:
+                    seen[a:a + na] += 1
+                pairs.append(sum(na * (n - a) - na * (na + 1) // 2 for a, na in blocks))
+            assert np.all(seen == 1)
+            assert sum(pairs) == n * (n - 1) // 2
+            if n >= 100_000:
+                assert max(pairs) / (sum(pairs) / world) < 1.02   # balanced
+
+
 def test_two_rank_gather_equals_single_process(oracle):
     import torch.multiprocessing as mp
     world, total, n, seed = 2, 37, 3000, 0x5EED
