@@ -112,6 +112,12 @@ int gw_table_geometry(const gw_table *t, gw_geometry *out);
 int gw_table_add_genotype_row(gw_table *t, uint64_t snp, const char *begin, const char *end,
                               char delim);
 int gw_table_flush(gw_table *t);
+/* The same for n_rows consecutive SNPs at once: rows[k] = [begins[k], ends[k]) is the genotype text
+ * of SNP snp_begin + k.  Rows are packed by n_threads host threads (0 = one per available core) and
+ * uploaded in chunks of up to 256 MB of packed rows; on GW_E_FORMAT the chunk holding the bad row and
+ * everything after it are not stored. */
+int gw_table_add_genotype_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const char *const *begins,
+                               const char *const *ends, char delim, int n_threads);
 
 /* Bulk hand-over of rows ALREADY in a reference packing (the bytes at
  * Table<DataBlock>::data, header block included, `row_stride_bytes` apart):

@@ -63,7 +63,7 @@ _lib = None
 # every extern "C" symbol include/gwas_scan.h declares
 EXPORTS = [
     "gw_last_error", "gw_version", "gw_device_count", "gw_device_info_get", "gw_table_create",
-    "gw_table_destroy", "gw_table_geometry", "gw_table_add_genotype_row", "gw_table_flush",
+    "gw_table_destroy", "gw_table_geometry", "gw_table_add_genotype_row", "gw_table_add_genotype_rows", "gw_table_flush",
     "gw_table_upload_rows", "gw_table_download_rows", "gw_table_get_headers", "gw_table_simulate",
     "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
@@ -92,6 +92,8 @@ def library() -> C.CDLL:
     L.gw_table_destroy.argtypes = [vp]
     L.gw_table_geometry.argtypes = [vp, C.POINTER(Geometry)]
     L.gw_table_add_genotype_row.argtypes = [vp, C.c_uint64, vp, vp, C.c_char]
+    L.gw_table_add_genotype_rows.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                             C.c_char, C.c_int]
     L.gw_table_flush.argtypes = [vp]
     L.gw_table_upload_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
     L.gw_table_download_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
@@ -212,6 +214,14 @@ class GwTable:
         buf = C.create_string_buffer(text, len(text))
         base = C.addressof(buf)
         _check(self._L.gw_table_add_genotype_row(self._h, snp, base, base + len(text), delim))
+
+    def add_genotype_rows(self, snp_begin: int, texts, delim: bytes = b"\t", n_threads: int = 0):
+        """Batch form: texts = list of bytes, one genotype row each, packed by n_threads host threads."""
+        n = len(texts)
+        bufs = [C.create_string_buffer(t, len(t)) for t in texts]
+        begins = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
+        ends = (C.c_char_p * n)(*[C.cast(C.addressof(b) + len(t), C.c_char_p) for b, t in zip(bufs, texts)])
+        _check(self._L.gw_table_add_genotype_rows(self._h, snp_begin, n, begins, ends, delim, n_threads))
 
     def flush(self):
         _check(self._L.gw_table_flush(self._h))

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gwas_scan.h"
@@ -420,6 +422,53 @@ int gw_table_add_genotype_row(gw_table *t, uint64_t snp, const char *begin, cons
                                  "spelling, more than three genotypes, or too many samples)",
                     (unsigned long long)snp);
     ++t->pending_rows;
+    return GW_OK;
+}
+
+int gw_table_add_genotype_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const char *const *begins,
+                               const char *const *ends, char delim, int n_threads) {
+    (void)delim;
+    if (!t || ((!begins || !ends) && n_rows)) return fail(GW_E_INVALID, "NULL argument");
+    int rc = check_range(t, snp_begin, n_rows);
+    if (rc) return rc;
+    if ((rc = gw_table_flush(t))) return rc;  // keep single-row additions ordered before the batch
+    if (n_rows == 0) return GW_OK;
+    unsigned workers = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
+    workers = (unsigned)std::min<uint64_t>(workers, n_rows);
+    const size_t row_blocks = t->geo.stream_row_bytes / 2u;
+    const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>(n_rows, (256u << 20) / t->geo.stream_row_bytes));
+    std::vector<uint16_t> packed;
+    try {
+        packed.resize((size_t)chunk_rows * row_blocks);
+    } catch (const std::bad_alloc &) {
+        return fail(GW_E_NOMEM, "out of host memory");
+    }
+    for (uint64_t done = 0; done < n_rows; done += chunk_rows) {
+        const uint64_t n = std::min<uint64_t>(chunk_rows, n_rows - done);
+        std::atomic<uint64_t> next(0);
+        std::atomic<long long> bad(-1);
+        auto work = [&]() {
+            for (;;) {
+                const uint64_t k = next.fetch_add(1);
+                if (k >= n) return;
+                if (!begins[done + k] || !ends[done + k] ||
+                    gw::pack_genotype_row(begins[done + k], ends[done + k], t->geo.n_samples, false,
+                                          packed.data() + (size_t)k * row_blocks) != 0) {
+                    long long expect = -1;
+                    bad.compare_exchange_strong(expect, (long long)(done + k));
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        if (bad.load() >= 0)
+            return fail(GW_E_FORMAT, "SNP %llu: genotype row the reference asserts on",
+                        (unsigned long long)(snp_begin + (uint64_t)bad.load()));
+        rc = gw_table_upload_rows(t, snp_begin + done, n, packed.data(), t->geo.stream_row_bytes, GW_LAYOUT_STREAM);
+        if (rc) return rc;
+    }
     return GW_OK;
 }
 

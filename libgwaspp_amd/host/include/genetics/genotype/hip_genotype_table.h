@@ -63,6 +63,8 @@ public:
     void selectCaseControl(CaseControlSet &ccs);
 
     // ---- batch extensions (what the per-row getters are served from)
+    // addGenotypeRow for rows rBegin, rBegin+1, ...: packed by all host cores, one upload
+    void addGenotypeRows(int rBegin, const std::vector<std::pair<const char *, const char *> > &rows, char delim);
     // association statistics of row r computed in the same kernel pass
     // (include/gwas_scan.h gw_scan_case_control: MAF x3, HWE x2, chi-square x2, call rate)
     const double *getAssociationStatistics(uint rIdx);

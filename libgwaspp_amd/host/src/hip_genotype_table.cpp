@@ -84,6 +84,15 @@ void HipGenotypeTable::addGenotypeRow(int rIdx, std::string::const_iterator &it,
     it = it_end;
 }
 
+void HipGenotypeTable::addGenotypeRows(int rBegin, const std::vector<std::pair<const char *, const char *> > &rows,
+                                       char delim) {
+    std::vector<const char *> b(rows.size()), e(rows.size());
+    for (size_t k = 0; k < rows.size(); ++k) { b[k] = rows[k].first; e[k] = rows[k].second; }
+    die_unless_ok(gw_table_add_genotype_rows(tbl, (uint64_t)rBegin, rows.size(), b.data(), e.data(), delim, 0),
+                  "addGenotypeRows");
+    invalidate();
+}
+
 void HipGenotypeTable::addGenotype(int rIdx, int cIdx, const std::string &gt) {
     // read-modify-write of one row in the reference's stream packing
     gw_geometry g;

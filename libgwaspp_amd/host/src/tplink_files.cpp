@@ -1,9 +1,14 @@
 // tplink_files.cpp -- see genetics/individual/tplink_files.h.
 #include "genetics/individual/tplink_files.h"
 
+#include <algorithm>
+#include <atomic>
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
+
+#include "genetics/genotype/hip_genotype_table.h"
 
 namespace libgwaspp {
 namespace genetics {
@@ -41,25 +46,24 @@ bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim) {
     }
     gd->createGenotypedMarkers(markers);
     gd->updateGenotypeTable();
-    // pass 2: genotype rows (parseNextGenotypeRecord, :127-190)
+    // pass 2: genotype rows (parseNextGenotypeRecord, :127-190), a batch of lines at a time: the
+    // lines are normalised ("A C A A ..." -> "AC<d>AA<d>...", 1..4 -> ACGT) by all host cores and
+    // handed to the table together
     in.clear();
     in.seekg(0, std::ios::beg);
     const size_t n = (size_t)gd->getGenotypedIndividualsCount();
-    std::string buf;
-    int row = 0;
-    while (std::getline(in, ln)) {
-        if (blank(ln)) continue;
-        size_t b = ln.find_first_not_of(" \t\r\n"), e = ln.find_last_not_of(" \t\r\n") + 1;
+    HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(gd->getGenotypeTable());
+    const size_t batch_lines = std::max<size_t>(1, std::min<size_t>(4096, (256u << 20) / (4 * n + 64)));
+    auto normalise = [n, delim](const std::string &line, std::string &buf) {
+        size_t b = line.find_first_not_of(" \t\r\n"), e = line.find_last_not_of(" \t\r\n") + 1;
         size_t pos = b;
         for (int seen = 0; seen < 4 && pos < e; ++pos)  // skip chrom, rs, distance, position
-            if (ln[pos] == ' ' || ln[pos] == '\t') ++seen;
-        // alleles sit two characters apart ("A C A A ..."): drop the blank inside
-        // each pair, put `delim` after it, map 1..4 to ACGT (:161-185)
+            if (line[pos] == ' ' || line[pos] == '\t') ++seen;
         buf.clear();
         buf.reserve(3 * n);
         bool second = false;
-        for (; pos < e; pos += 2) {
-            char c = ln[pos];
+        for (; pos < e; pos += 2) {  // alleles sit two characters apart (:161-185)
+            char c = line[pos];
             switch (c) {
             case '1': c = 'A'; break;
             case '2': c = 'C'; break;
@@ -71,7 +75,35 @@ bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim) {
             if (second) buf.push_back(delim);
             second = !second;
         }
-        gd->addGenotypeRow(row++, buf.data(), buf.data() + buf.size(), delim);
+    };
+    std::vector<std::string> lines, texts;
+    int row = 0;
+    bool eof = false;
+    while (!eof) {
+        lines.clear();
+        while (lines.size() < batch_lines) {
+            if (!std::getline(in, ln)) { eof = true; break; }
+            if (!blank(ln)) lines.push_back(ln);
+        }
+        if (lines.empty()) break;
+        texts.resize(lines.size());
+        unsigned workers = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)lines.size()));
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (size_t k; (k = next.fetch_add(1)) < lines.size();) normalise(lines[k], texts[k]);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        if (hip) {
+            std::vector<std::pair<const char *, const char *> > rows(texts.size());
+            for (size_t k = 0; k < texts.size(); ++k) rows[k] = std::make_pair(texts[k].data(), texts[k].data() + texts[k].size());
+            hip->addGenotypeRows(row, rows, delim);
+            row += (int)texts.size();
+        } else {
+            for (const std::string &t : texts) gd->addGenotypeRow(row++, t.data(), t.data() + t.size(), delim);
+        }
     }
     return true;
 }

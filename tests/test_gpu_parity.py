@@ -324,3 +324,30 @@ def test_complementary_mask_kernel(oracle, n, m):
             counts, stats = t.scan_case_control()
             assert np.array_equal(counts, wc)
             _assert_stats(stats, ws)
+
+
+def test_batch_text_ingest(oracle):
+    """gw_table_add_genotype_rows: many rows packed by host threads == row-at-a-time ingest == oracle."""
+    n, m = 777, 300
+    rng = np.random.default_rng(3)
+    codes = _random_codes(rng, m, n, p_missing=0.1)
+    codes[:, 0], codes[:, 1], codes[:, 2] = 1, 2, 3
+    texts = [oracle.codes_to_text(codes[r]) for r in range(m)]
+    want = oracle.pack_rows(texts, n)
+    with gw.GwTable(n, m + 5) as t:
+        t.add_genotype_rows(2, texts, n_threads=5)
+        assert np.array_equal(t.download_rows(2, m), want)
+        assert not t.download_rows(0, 2).any() and not t.download_rows(m + 2, 3).any()
+        # mixing with the row-at-a-time form keeps the order of writes
+        t.add_genotype_row(2, texts[7])
+        t.add_genotype_rows(3, texts[:2])
+        got = t.download_rows(2, 3)
+        assert np.array_equal(got[0], want[7]) and np.array_equal(got[1:], want[:2])
+        # a row the reference asserts on: error names the SNP, earlier content stays
+        bad = list(texts[:4]) + [b"AC\tCA\t"]
+        with pytest.raises(gw.GwError) as e:
+            t.add_genotype_rows(10, bad)
+        assert e.value.code == -6 and "SNP 14" in str(e.value)
+        with pytest.raises(gw.GwError) as e:
+            t.add_genotype_rows(m + 3, texts[:5])   # runs past the table
+        assert e.value.code == -5
