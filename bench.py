@@ -404,7 +404,11 @@ def main():
                  "mask_in_lds": table.get_option(capi.OPT_MASK_IN_LDS),
                  "block_threads": table.get_option(capi.OPT_BLOCK_THREADS),
                  "blocks_per_cu": table.get_option(capi.OPT_BLOCKS_PER_CU),
-                 "nontemporal": table.get_option(capi.OPT_NONTEMPORAL)}
+                 "nontemporal": table.get_option(capi.OPT_NONTEMPORAL),
+                 "continuous_stream": table.get_option(capi.OPT_PIPELINE),
+                 "single_mask": table.get_option(capi.OPT_COMPLEMENT)}
+        kernel_name = ("gw::k_scan_cc_compl" if shape["single_mask"] else
+                       "gw::k_scan_cc_pipe" if shape["continuous_stream"] else "gw::k_scan_cc")
         out = {
             "metric": "SNPs/sec case/control chi2 scan",
             "value": total_snps / (elapsed / args.steps),
@@ -430,7 +434,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
-                "kernel": "gw::k_scan_cc", "kernel_ms": kernel_ms, "launches_timed": launches,
+                "kernel": kernel_name, "kernel_ms": kernel_ms, "launches_timed": launches,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "stream_read_probe_GBps": probe_gbps,
                 "frac_of_probe": (achieved / probe_gbps) if probe_gbps else None,

@@ -252,8 +252,10 @@ typedef enum gw_option {
                                 can stage one mask in LDS and take controls = all - cases: 0 never,
                                 1 (default) only where two masks do not fit the LDS (650 k < N <= 1.3 M),
                                 2 whenever possible; get returns whether the current masks/shape use it */
-    GW_OPT_PIPELINE = 6      /* 1: next step's loads issued before the current step is consumed,
-                                across row boundaries; 0: row-at-a-time kernel (default) */
+    GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
+                                is consumed, across row boundaries; inline-asm loads + counted waits):
+                                -1 (default) auto = where the masks allow one workgroup per CU only
+                                (N > ~320 k), 0 never, 1 whenever the masks are in LDS */
 } gw_option;
 int gw_set_option(gw_table *t, int option, int64_t value);
 int gw_get_option(gw_table *t, int option, int64_t *value);

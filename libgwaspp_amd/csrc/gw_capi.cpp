@@ -83,7 +83,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = 0, opt_complement = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1;
 };
 
 namespace {
@@ -97,13 +97,13 @@ hipStream_t pick_stream(gw_table *t, void *s) { return s ? (hipStream_t)s : t->s
 
 gw::ScanShape scan_shape(const gw_table *t) {
     // Defaults from the round-1 sweeps on MI355X (profiles/r01_sweep_*.txt):
-    //   masks fill more than half the LDS (N > ~320 k): one 512-thread workgroup per CU,
-    //     2 units per lane per plane in flight -- fewer, fatter streams read HBM best;
+    //   masks fill more than half the LDS (N > ~320 k): one 256-thread workgroup per CU (one wave per
+    //     SIMD) running the continuous-stream kernel with two 2-unit buffers per lane and plane --
+    //     fewer, fatter streams read HBM best (without it: 512 threads, 2 units in flight);
     //   masks fit several times: 1024-thread workgroups, 1 unit in flight, up to 4 per CU;
     //   masks do not fit (N > ~650 k): read through L2, 4 units in flight;
     //   short rows (N <= ~32 k): 256-thread workgroups, 8 per CU.
     gw::ScanShape sh{};
-    sh.pipeline = t->opt_pipeline;
     sh.nontemporal = t->opt_nt;
     const bool want_lds = (t->opt_mask_lds < 0) ? true : (t->opt_mask_lds != 0);
     // single-mask kernel when the control mask is the complement of the case mask
@@ -111,16 +111,28 @@ gw::ScanShape scan_shape(const gw_table *t) {
     // (auto: only where two masks do not fit the LDS -- 650 k < N <= 1.3 M, 86 % vs 75 % of the HBM
     // peak measured at N = 1 M; where both fit the two kernels run at the same speed)
     const bool compl_wanted = t->opt_complement == 2 || (t->opt_complement == 1 && 2 * one_mask > t->lds_cap);
-    const bool compl_ok = compl_wanted && t->masks_complementary && want_lds && t->opt_nt && !t->opt_pipeline &&
+    const bool compl_ok = compl_wanted && t->masks_complementary && want_lds && t->opt_nt && t->opt_pipeline != 1 &&
                           one_mask <= t->lds_cap;
     const size_t raw_need = compl_ok ? one_mask : 2 * one_mask;
     bool lds = want_lds && raw_need <= t->lds_cap;
     const bool one_per_cu = lds && 2 * raw_need > t->lds_cap;
+    // continuous-stream (asm-pipelined) kernel: auto = where one workgroup per CU is all the LDS allows
+    // (N > ~320 k): 4 waves per CU, one per SIMD, two 2-unit buffers in flight -- 87 % vs 85 % at c3
+    sh.pipeline = t->opt_pipeline < 0 ? ((one_per_cu && !compl_ok && lds) ? 1 : 0) : (t->opt_pipeline && lds && !compl_ok);
     int unroll = t->opt_unroll ? t->opt_unroll : (!lds ? 4 : (one_per_cu ? 2 : 1));
-    // the continuous-stream kernel keeps the masks zero-padded to a whole step in LDS
-    const uint32_t step = 64u * (uint32_t)unroll;
-    const uint32_t lds_units = sh.pipeline ? ((t->tv.units + step - 1u) / step) * step : t->tv.units;
-    const size_t need = compl_ok ? one_mask : (size_t)2 * lds_units * sizeof(gw::u32x4);
+    // the continuous-stream kernel exists for 1, 2, 4 units and keeps the masks zero-padded to a
+    // whole step in LDS; if that padding no longer fits, fall back to the row-at-a-time kernel
+    if (sh.pipeline) {
+        if (unroll > 4) unroll = 4;
+        const uint32_t step = 64u * (uint32_t)unroll;
+        const size_t padded = (size_t)2 * (((t->tv.units + step - 1u) / step) * step) * sizeof(gw::u32x4);
+        if (padded > t->lds_cap) sh.pipeline = 0;
+    }
+    size_t need = raw_need;
+    if (sh.pipeline) {
+        const uint32_t step = 64u * (uint32_t)unroll;
+        need = (size_t)2 * (((t->tv.units + step - 1u) / step) * step) * sizeof(gw::u32x4);
+    }
     if (lds && need > t->lds_cap) lds = false;
     sh.complement = (compl_ok && lds) ? 1 : 0;
     sh.mask_in_lds = lds ? 1 : 0;
@@ -128,7 +140,9 @@ gw::ScanShape scan_shape(const gw_table *t) {
     sh.unroll = unroll;
     const int lds_limit = lds ? (int)(t->lds_cap / need) : 8;
     const bool short_rows = t->tv.units <= 256u;  // N <= ~32 k: rows of one or two wave-steps
-    int threads = t->opt_threads ? t->opt_threads : (one_per_cu ? 512 : (short_rows ? 256 : 1024));
+    int threads = t->opt_threads ? t->opt_threads
+                                 : (one_per_cu ? (sh.pipeline ? 256 : 512) : (short_rows ? 256 : 1024));
+    if (sh.pipeline && threads > 512) threads = 512;  // k_scan_cc_pipe is built for <= 512 threads
     int per_cu = t->opt_blocks_per_cu ? t->opt_blocks_per_cu : (one_per_cu ? 1 : (short_rows ? 8 : 4));
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
@@ -933,7 +947,8 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_threads = (int)v;
         return GW_OK;
     case GW_OPT_PIPELINE:
-        t->opt_pipeline = v ? 1 : 0;
+        if (v < -1 || v > 1) return fail(GW_E_INVALID, "pipeline must be -1 (auto), 0 or 1");
+        t->opt_pipeline = (int)v;
         return GW_OK;
     case GW_OPT_COMPLEMENT:
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "complement must be 0 (never), 1 (auto) or 2 (whenever possible)");

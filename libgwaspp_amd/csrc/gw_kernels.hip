@@ -329,28 +329,54 @@ __global__ void __launch_bounds__(1024) k_scan_cc_compl(ScanArgs a) {
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
-// One step = UNROLL 1-KiB wave-loads per plane.  Never predicated: a lane past
-// the end of the row re-reads the row's last unit (its mask words are zero), so
-// that the compiler can count the loads in flight and wait for exactly the
-// older buffer (a load under a divergent branch forces vmcnt(0)).
+// ---------------------------------------------------------------------------
+// Continuous-stream form of the scan (GW_OPT_PIPELINE): the loads of the NEXT
+// (row, step) item are in flight while the current one is consumed, also across
+// the row boundary.  hipcc cannot be made to do this with ordinary loads (it
+// re-uses in-flight destination registers as temporaries and falls back to
+// vmcnt(0)), so the genotype stream is loaded with inline asm and waited for
+// with hand-counted s_waitcnt vmcnt(N):
+//   * a load's destination is unprotected until the wait that covers it; the
+//     wait statement takes the buffer as a read-write operand, so every use of
+//     the data depends on it;
+//   * loads are never predicated (a lane past the row's end re-reads the last
+//     unit; its mask words are zero) and the item after the wave's last one
+//     re-reads the current row, so the number of loads in flight is exact;
+//   * vmcnt counts in issue order, stores included: a wait written for "the
+//     other buffer's 2*UNROLL loads may remain" can only over-wait when the
+//     64-row epilogue's stores sit in between, never under-wait.
+// ---------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ void asm_load(u32x4 &dst, const u32x4 *p) {
+    if (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+
 template <int UNROLL, bool NT>
-__device__ __forceinline__ void load_step(const u32x4 *p0, const u32x4 *p1, uint32_t first, uint32_t lane,
-                                          uint32_t last_unit, u32x4 (&A)[UNROLL], u32x4 (&B)[UNROLL]) {
+__device__ __forceinline__ void asm_load_step(const u32x4 *p0, const u32x4 *p1, uint32_t first, uint32_t lane,
+                                              uint32_t last_unit, u32x4 (&A)[UNROLL], u32x4 (&B)[UNROLL]) {
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
         const uint32_t u = min(first + 64u * k + lane, last_unit);
-        A[k] = ld_stream<NT>(p0 + u);
-        B[k] = ld_stream<NT>(p1 + u);
+        asm_load<NT>(A[k], p0 + u);
+        asm_load<NT>(B[k], p1 + u);
     }
 }
 
-// Continuous-stream form of the scan: the loads of the NEXT step -- the next
-// step of this row or the first step of the wave's next row -- are issued
-// before the current step is consumed, so the HBM stream never drains across
-// the per-row reduction and FP64 epilogue.  Same ownership (one wave per row),
-// same results.
+// wait until at most 2*UNROLL vector-memory operations are outstanding, i.e.
+// until buffer (A, B) -- issued before the other buffer's 2*UNROLL loads -- has landed
+template <int UNROLL>
+__device__ __forceinline__ void asm_wait_older(u32x4 (&A)[UNROLL], u32x4 (&B)[UNROLL]) {
+    static_assert(UNROLL == 1 || UNROLL == 2 || UNROLL == 4, "pipelined scan: 1, 2 or 4 units per lane");
+    if (UNROLL == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(A[0]), "+v"(B[0]));
+    if (UNROLL == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(A[0]), "+v"(B[0]), "+v"(A[1]), "+v"(B[1]));
+    if (UNROLL == 4)
+        asm volatile("s_waitcnt vmcnt(8)"
+                     : "+v"(A[0]), "+v"(B[0]), "+v"(A[1]), "+v"(B[1]), "+v"(A[2]), "+v"(B[2]), "+v"(A[3]), "+v"(B[3]));
+}
+
 template <int UNROLL, bool MASK_LDS, bool NT>
-__global__ void __launch_bounds__(1024) k_scan_cc_pipe(ScanArgs a) {
+__global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 threads: up to 256 VGPRs for the two buffers
     extern __shared__ u32x4 lds_masks[];  // [2][steps * STEP] when MASK_LDS, zero past `units`
     const uint32_t units = a.units;
     constexpr uint32_t STEP = 64u * UNROLL;
@@ -368,20 +394,19 @@ __global__ void __launch_bounds__(1024) k_scan_cc_pipe(ScanArgs a) {
         mctrl = lds_masks + padded;
     }
     const uint32_t lane = threadIdx.x & 63u;
-    // wave-uniform values kept in SGPRs: row indices and row base addresses are scalar arithmetic
+    // the row walk lives in SGPRs: row indices, base addresses and branches are scalar
     const uint32_t waves_per_block = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t total_waves = __builtin_amdgcn_readfirstlane(gridDim.x * waves_per_block);
     const uint32_t last_unit = units - 1u;
 
-    // The wave's work is one flat sequence of (row, step) items; two register
-    // buffers ping-pong so that item i+1 is always in flight while item i is
-    // consumed, also across the row boundary (reduction + FP64 epilogue).
     uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * waves_per_block + wave);
     if (r >= a.n_rows) return;  // no barrier below
     uint32_t s = 0;
     u32x4 A0[UNROLL], B0[UNROLL], A1[UNROLL], B1[UNROLL];
     uint32_t c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t mine[6] = {0, 0, 0, 0, 0, 0};  // finished rows parked one per lane, epilogue per 64 rows
+    uint32_t my_row = 0xFFFFFFFFu, slot = 0;
 
     auto consume = [&](const u32x4 (&A)[UNROLL], const u32x4 (&B)[UNROLL], uint32_t row, uint32_t step) {
 #pragma unroll
@@ -393,35 +418,39 @@ __global__ void __launch_bounds__(1024) k_scan_cc_pipe(ScanArgs a) {
             else acc_unit(A[k], B[k], mc, mt, c0);
         }
         if (step + 1u == steps) {  // wave-uniform: the row is complete
-            uint32_t sum[6];
+            const bool park = lane == slot;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                sum[j] = wave_sum_dpp(c0[j] + c1[j]);
+                const uint32_t total = wave_sum_dpp(c0[j] + c1[j]);
+                mine[j] = park ? total : mine[j];
                 c0[j] = 0;
                 c1[j] = 0;
             }
-            if (lane == 0) finish_row(a, row, sum);
+            my_row = park ? row : my_row;
+            if (++slot == 64u) {
+                finish_row(a, my_row, mine);
+                my_row = 0xFFFFFFFFu;
+                slot = 0;
+            }
         }
     };
 
     {
         const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
-        load_step<UNROLL, NT>(p0, p0 + a.plane_stride_u, 0, lane, last_unit, A0, B0);
+        asm_load_step<UNROLL, NT>(p0, p0 + a.plane_stride_u, 0, lane, last_unit, A0, B0);
     }
     for (;;) {
-        // item after (r, s).  Its loads are issued unconditionally -- past the
-        // wave's last row they re-read the current row (a few KiB per wave per
-        // launch) -- because a conditionally issued load makes the load count
-        // unknown to the compiler, which then waits for vmcnt(0).
+        // item after (r, s); past the wave's last row the loads re-read the current row
         uint32_t r1 = r, s1 = s + 1u;
         if (s1 == steps) { r1 = r + total_waves; s1 = 0; }
-        r1 = __builtin_amdgcn_readfirstlane(r1);  // the row walk stays in SGPRs
+        r1 = __builtin_amdgcn_readfirstlane(r1);
         s1 = __builtin_amdgcn_readfirstlane(s1);
         const bool have1 = r1 < a.n_rows;
         {
             const u32x4 *q0 = a.table + (a.row_begin + (have1 ? r1 : r)) * a.row_stride_u;
-            load_step<UNROLL, NT>(q0, q0 + a.plane_stride_u, s1 * STEP, lane, last_unit, A1, B1);
+            asm_load_step<UNROLL, NT>(q0, q0 + a.plane_stride_u, s1 * STEP, lane, last_unit, A1, B1);
         }
+        asm_wait_older<UNROLL>(A0, B0);
         consume(A0, B0, r, s);
         if (!have1) break;
         // item after (r1, s1)
@@ -432,19 +461,23 @@ __global__ void __launch_bounds__(1024) k_scan_cc_pipe(ScanArgs a) {
         const bool have2 = r2 < a.n_rows;
         {
             const u32x4 *t0 = a.table + (a.row_begin + (have2 ? r2 : r1)) * a.row_stride_u;
-            load_step<UNROLL, NT>(t0, t0 + a.plane_stride_u, s2 * STEP, lane, last_unit, A0, B0);
+            asm_load_step<UNROLL, NT>(t0, t0 + a.plane_stride_u, s2 * STEP, lane, last_unit, A0, B0);
         }
+        asm_wait_older<UNROLL>(A1, B1);
         consume(A1, B1, r1, s1);
         if (!have2) break;
         r = r2;
         s = s2;
     }
+    // the loads issued for the item that does not exist must land before the registers die
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
 template <int UNROLL, bool MASK_LDS, bool NT>
 static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
-    if (sh.pipeline)
-        hipLaunchKernelGGL((k_scan_cc_pipe<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
+    if (sh.pipeline && UNROLL <= 4)
+        hipLaunchKernelGGL((k_scan_cc_pipe<(UNROLL <= 4 ? UNROLL : 4), MASK_LDS, NT>), dim3(sh.grid_blocks),
                            dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
     else
         hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
@@ -506,10 +539,11 @@ static hipError_t prepare_u(size_t bytes) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<UNROLL, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<UNROLL, true, true>),
+    constexpr int PU = UNROLL <= 4 ? UNROLL : 4;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<PU, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<UNROLL, true, false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_pipe<PU, true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 

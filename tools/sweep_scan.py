@@ -27,7 +27,7 @@ ap.add_argument("--threads", default="256,512,1024")
 ap.add_argument("--per-cu", default="0")
 ap.add_argument("--lds", default="1")
 ap.add_argument("--nt", default="1")
-ap.add_argument("--pipe", default="0")
+ap.add_argument("--pipe", default="-1", help="-1 auto, 0 row-at-a-time, 1 continuous-stream")
 ap.add_argument("--compl", default="1", help="0 never, 1 auto, 2 whenever possible")
 ap.add_argument("--stats", type=int, default=1)
 args = ap.parse_args()
