@@ -305,8 +305,13 @@ def main():
         if world > 1 and rank == 0:
             gathers.append([torch.empty(rows * RECORD_BYTES, dtype=torch.uint8, device="cuda")
                             for _ in range(world)])
-    stream = torch.cuda.current_stream()
+    # An explicit (non-default) torch stream: the scans are launched on it through the C-ABI and RCCL
+    # orders each gather behind it.  (The default stream's handle is 0, which the C-ABI reads as "the
+    # table's own stream" -- RCCL would then not wait for the scan.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
+    assert sptr != 0
 
     # the exchange step: per-SNP records to rank 0.  gather = grouped send/recv in RCCL, each
     # slice over its own xGMI link; if this RCCL build refuses gather, fall back to all_gather
