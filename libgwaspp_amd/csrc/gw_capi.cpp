@@ -631,7 +631,9 @@ int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     if (rc) return rc;
     if ((rc = gw_table_flush(t))) return rc;
     if ((rc = use_device(t))) return rc;
-    GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, t->compute_units,
+    // 512-thread workgroups: one per CU for long rows (few, fat streams), more for short ones
+    const int per_cu = t->tv.units <= 256u ? 4 : (t->tv.units < 2000u ? 2 : 1);
+    GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, t->compute_units * per_cu,
                                 pick_stream(t, hip_stream)));
     return GW_OK;
 }

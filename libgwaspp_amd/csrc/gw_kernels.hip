@@ -569,23 +569,24 @@ __global__ void __launch_bounds__(1024) k_scan_dist(const u32x4 *table, uint64_t
                                                     uint32_t n_rows, uint32_t *dist) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
-    constexpr uint32_t STEP = 256u;
+    constexpr int U = 2;  // 512-thread workgroups, 2 units per lane and plane in flight (profiles/r01_read_patterns_*)
+    constexpr uint32_t STEP = 64u * U;
     const uint32_t full = (units / STEP) * STEP;
     for (uint32_t r = gwave; r < n_rows; r += total_waves) {
         const u32x4 *p0 = table + (row_begin + r) * row_stride_u;
         const u32x4 *p1 = p0 + plane_stride_u;
         uint32_t c[3] = {0, 0, 0};
         for (uint32_t base = 0; base < full; base += STEP) {
-            u32x4 A[4], B[4];
+            u32x4 A[U], B[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < U; ++k) {
                 A[k] = ld_stream<true>(p0 + base + 64u * k + lane);
                 B[k] = ld_stream<true>(p1 + base + 64u * k + lane);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < U; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     c[0] += __popc(A[k][j]);
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(1024) k_scan_dist(const u32x4 *table, uint64_t
                 c[2] += __popc(A[j] & B[j]);
             }
         }
-        const uint32_t s0 = wave_sum(c[0]), s1 = wave_sum(c[1]), s2 = wave_sum(c[2]);
+        const uint32_t s0 = wave_sum_dpp(c[0]), s1 = wave_sum_dpp(c[1]), s2 = wave_sum_dpp(c[2]);
         if (lane == 0) {
             const uint32_t aa = s0 - s2, ab = s1 - s2, bb = s2;
             u32x4 v = {aa, ab, bb, n_samples - aa - ab - bb};
@@ -614,7 +615,7 @@ __global__ void __launch_bounds__(1024) k_scan_dist(const u32x4 *table, uint64_t
 hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
                             uint32_t *d_dist, int grid_blocks, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_dist, dim3(grid_blocks), dim3(1024), 0, stream, tv.base,
+    hipLaunchKernelGGL(k_scan_dist, dim3(grid_blocks), dim3(512), 0, stream, tv.base,
                        tv.row_stride_u, tv.plane_stride_u, tv.units, tv.n_samples, row_begin,
                        n_rows, d_dist);
     return hipGetLastError();
