@@ -111,3 +111,17 @@ def test_mask_builder_edges():
     assert e.value.code == -5
     m, cnt = gw.build_stream_mask([], 10)
     assert cnt == 0 and not m.any()
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/gwas_scan.h compiles as C99 and the library links from a C program
+    (examples/scan_demo.c); its GPU-free half runs here."""
+    import subprocess
+    exe = str(tmp_path / "scan_demo")
+    pkg = os.path.join(ROOT, "libgwaspp_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "scan_demo.c"), "-L" + pkg, "-lgwscan", "-Wl,-rpath," + pkg,
+                    "-o", exe], check=True)
+    out = subprocess.run([exe, "--host-only"], check=True, capture_output=True, text=True).stdout
+    assert "row 0 header 0x7015" in out          # AA first, then AC, then CC
+    assert "case mask 0x0055 (4)" in out and "control mask 0x00aa (4)" in out

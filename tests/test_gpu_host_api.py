@@ -194,3 +194,17 @@ def test_compute_boost_report(oracle, tmp_path):
         assert float(got[3]) == 0.0 and float(got[4]) == 0.0
         assert float(got[5]) == pytest.approx(w[2], abs=2e-6)
         assert float(got[6]) == pytest.approx(w[3], abs=2e-6)
+
+
+def test_plain_c_example_runs(tmp_path):
+    """examples/scan_demo.c end to end on the GPU (C99 caller of the C-ABI)."""
+    exe = str(tmp_path / "scan_demo")
+    pkg = os.path.join(ROOT, "libgwaspp_amd")
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "scan_demo.c"),
+                    "-L" + pkg, "-lgwscan", "-Wl,-rpath," + pkg, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    lines = [ln for ln in out.splitlines() if ln.startswith("SNP ")]
+    assert len(lines) == 3
+    # SNP 0: samples 0,2,4,6 are cases: AA CC 00 AA -> aa 2, bb 1, xx 1; controls AC AA AC CC -> aa 1, ab 2, bb 1
+    assert "SNP 0  cases aa/ab/bb/xx 2 0 1 1  controls 1 2 1 0" in lines[0]
+    assert "SNP 2  cases aa/ab/bb/xx 4 0 0 0  controls 4 0 0 0" in lines[2]
