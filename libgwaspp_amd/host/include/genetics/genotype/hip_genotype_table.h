@@ -71,6 +71,8 @@ public:
     // many pairs in one launch; out = n x 16 (and n x 16 for controls)
     void getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
                                          std::vector<uint> &cases, std::vector<uint> &ctrls);
+    // getContingencyTable for many pairs in one launch; out = n x 16
+    void getContingencyTables(const uint *pairs, size_t n_pairs, std::vector<uint> &tables);
     // computeBoost's whole pre-screening loop (algorithms/epistasis_func.cpp:393-486) in one device
     // pass: pairs (i, j, measure) with measure > threshold, in the reference's (i, j) visiting order
     void boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing);

@@ -294,6 +294,11 @@ void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t
                   "gw_pair_case_control_contingency");
 }
 
+void HipGenotypeTable::getContingencyTables(const uint *pairs, size_t n_pairs, std::vector<uint> &tables) {
+    tables.resize(n_pairs * 16);
+    die_unless_ok(gw_pair_contingency(tbl, pairs, n_pairs, tables.data()), "gw_pair_contingency");
+}
+
 void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing) {
     if (!installed) std::abort();
     passing.clear();

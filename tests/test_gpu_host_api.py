@@ -208,3 +208,13 @@ def test_plain_c_example_runs(tmp_path):
     # SNP 0: samples 0,2,4,6 are cases: AA CC 00 AA -> aa 2, bb 1, xx 1; controls AC AA AC CC -> aa 1, ab 2, bb 1
     assert "SNP 0  cases aa/ab/bb/xx 2 0 1 1  controls 1 2 1 0" in lines[0]
     assert "SNP 2  cases aa/ab/bb/xx 4 0 0 0  controls 4 0 0 0" in lines[2]
+
+
+def test_contingency_performance_harness():
+    """--contin-perform: every pair's 4x4 table (batched on the device); each table sums to the
+    table's 64-bit-word capacity (pad bits land in xx_xx, table5.cpp:749-800)."""
+    name = "plain_m40_n70"
+    out = _run(name, "--contin-perform")
+    line = [ln for ln in out.splitlines() if ln.startswith("Contingencies 40:")][0]
+    words = (((70 // 16 + 1) + 3) & ~3) // 4
+    assert f"(sum of all cells {40 * 39 // 2 * words * 64})" in line
