@@ -232,9 +232,10 @@ class GwTable:
         _check(self._L.gw_table_upload_rows(self._h, snp_begin, rows.shape[0], rows.ctypes.data,
                                             rows.shape[1] * 2, layout))
 
-    def download_rows(self, snp_begin: int, n_rows: int, layout: int = LAYOUT_STREAM) -> np.ndarray:
+    def download_rows(self, snp_begin: int, n_rows: int, layout: int = LAYOUT_STREAM, pad_blocks: int = 0) -> np.ndarray:
+        """rows in a reference packing; pad_blocks > 0 asks for a pitched destination (extra uint16 per row)."""
         g = self.geometry
-        nb = (g.stream_row_bytes if layout == LAYOUT_STREAM else g.block_row_bytes) // 2
+        nb = (g.stream_row_bytes if layout == LAYOUT_STREAM else g.block_row_bytes) // 2 + pad_blocks
         rows = np.zeros((n_rows, nb), dtype=np.uint16)
         _check(self._L.gw_table_download_rows(self._h, snp_begin, n_rows, rows.ctypes.data, nb * 2, layout))
         return rows

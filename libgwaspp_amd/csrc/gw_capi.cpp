@@ -60,6 +60,7 @@ struct gw_table {
     std::vector<uint16_t> headers;  // row header blocks (table5.cpp:363)
 
     uint8_t *d_staging = nullptr;  // reference-packed rows in flight to/from HBM
+    uint8_t *h_pinned = nullptr;   // pinned host twin of d_staging (pitched sources / destinations)
     size_t staging_bytes = 0;
     uint32_t *d_scratch32 = nullptr;  // results of the host-pointer scan forms
     size_t scratch32_bytes = 0;
@@ -321,6 +322,7 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_case) (void)hipFree(t->d_case);
     if (t->d_ctrl) (void)hipFree(t->d_ctrl);
     if (t->d_staging) (void)hipFree(t->d_staging);
+    if (t->h_pinned) (void)hipHostFree(t->h_pinned);
     if (t->d_scratch32) (void)hipFree(t->d_scratch32);
     if (t->d_scratch64) (void)hipFree(t->d_scratch64);
     if (t->d_misc) (void)hipFree(t->d_misc);
@@ -360,8 +362,17 @@ int gw_table_upload_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, const
     const uint8_t *src = static_cast<const uint8_t *>(rows);
     for (uint64_t done = 0; done < n_rows; done += chunk_rows) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, n_rows - done);
-        GW_HIP(hipMemcpy2DAsync(t->d_staging, ref_bytes, src + done * row_stride_bytes, row_stride_bytes,
-                                ref_bytes, n, hipMemcpyHostToDevice, t->stream));
+        // rows that lie back to back go over as one transfer; a pitched source is gathered row by row
+        // (a 2-D copy from pageable memory crawls at well under 1 GB/s)
+        if (row_stride_bytes == ref_bytes) {
+            GW_HIP(hipMemcpyAsync(t->d_staging, src + done * row_stride_bytes, (size_t)n * ref_bytes,
+                                  hipMemcpyHostToDevice, t->stream));
+        } else {
+            if (!t->h_pinned) GW_HIP(hipHostMalloc((void **)&t->h_pinned, t->staging_bytes, hipHostMallocDefault));
+            for (uint32_t r = 0; r < n; ++r)
+                std::memcpy(t->h_pinned + (size_t)r * ref_bytes, src + (done + r) * row_stride_bytes, ref_bytes);
+            GW_HIP(hipMemcpyAsync(t->d_staging, t->h_pinned, (size_t)n * ref_bytes, hipMemcpyHostToDevice, t->stream));
+        }
         t->selected_valid = false;
         GW_HIP(gw::launch_restride_in(t->tv, snp_begin + done, n, t->d_staging, ref_bytes, layout,
                                       ref_blocks, t->stream));
@@ -394,9 +405,17 @@ int gw_table_download_rows(gw_table *t, uint64_t snp_begin, uint64_t n_rows, voi
         const uint32_t n = (uint32_t)std::min<uint64_t>(chunk_rows, n_rows - done);
         GW_HIP(gw::launch_restride_out(t->tv, snp_begin + done, n, t->d_staging, ref_bytes, layout,
                                        ref_blocks, t->stream));
-        GW_HIP(hipMemcpy2DAsync(dst + done * row_stride_bytes, row_stride_bytes, t->d_staging, ref_bytes,
-                                ref_bytes, n, hipMemcpyDeviceToHost, t->stream));
-        GW_HIP(hipStreamSynchronize(t->stream));
+        if (row_stride_bytes == ref_bytes) {
+            GW_HIP(hipMemcpyAsync(dst + done * row_stride_bytes, t->d_staging, (size_t)n * ref_bytes,
+                                  hipMemcpyDeviceToHost, t->stream));
+            GW_HIP(hipStreamSynchronize(t->stream));
+        } else {
+            if (!t->h_pinned) GW_HIP(hipHostMalloc((void **)&t->h_pinned, t->staging_bytes, hipHostMallocDefault));
+            GW_HIP(hipMemcpyAsync(t->h_pinned, t->d_staging, (size_t)n * ref_bytes, hipMemcpyDeviceToHost, t->stream));
+            GW_HIP(hipStreamSynchronize(t->stream));
+            for (uint32_t r = 0; r < n; ++r)
+                std::memcpy(dst + (done + r) * row_stride_bytes, t->h_pinned + (size_t)r * ref_bytes, ref_bytes);
+        }
         for (uint32_t r = 0; r < n; ++r)
             std::memcpy(dst + (done + r) * row_stride_bytes, &t->headers[snp_begin + done + r], 2);
     }

@@ -351,3 +351,20 @@ def test_batch_text_ingest(oracle):
         with pytest.raises(gw.GwError) as e:
             t.add_genotype_rows(m + 3, texts[:5])   # runs past the table
         assert e.value.code == -5
+
+
+@pytest.mark.parametrize("layout,lname", [(gw.LAYOUT_STREAM, "stream"), (gw.LAYOUT_BLOCK, "block")])
+def test_pitched_row_buffers(oracle, layout, lname):
+    """rows `row_stride_bytes` apart with slack between them (a caller's own allocation), both ways."""
+    n, m = 1234, 77
+    rng = np.random.default_rng(8)
+    table = oracle.pack_codes(_random_codes(rng, m, n), lname)
+    wide = np.full((m, table.shape[1] + 5), 0xDEAD, dtype=np.uint16)
+    wide[:, :table.shape[1]] = table
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, wide, layout)
+        assert np.array_equal(t.download_rows(0, m, layout), table)
+        back = t.download_rows(0, m, layout, pad_blocks=3)
+        assert np.array_equal(back[:, :table.shape[1]], table) and not back[:, table.shape[1]:].any()
+        with pytest.raises(gw.GwError):   # a stride shorter than a row
+            t.upload_rows(0, table[:, :-1].copy(), layout)
