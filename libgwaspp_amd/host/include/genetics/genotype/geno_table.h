@@ -1,7 +1,10 @@
-// genetics/genotype/geno_table.h -- THE DROP-IN BOUNDARY: the abstract genotype
-// table of the reference (genotype/geno_table.h:47-87) = Table<DataBlock> +
-// SingleMarkerAnalyzable + PairwiseMarkerAnalyzable + CaseControlSelectable.
-// HipGenotypeTable (hip_genotype_table.h) is the MI355X implementation.
+// genetics/genotype/geno_table.h -- THE DROP-IN BOUNDARY.
+//
+// The reference's abstract genotype table (genotype/geno_table.h:47-87): storage contract
+// (util::Table<DataBlock>) + per-SNP operators (SingleMarkerAnalyzable) + SNP-pair operators
+// (PairwiseMarkerAnalyzable) + phenotype selection (CaseControlSelectable).  A table implementation
+// supplies ingest, the genotype vocabulary and the operators; GeneticData picks the implementation
+// (genetic_data.cpp:46-80).  HipGenotypeTable (hip_genotype_table.h) is the MI355X one.
 #pragma once
 #include <string>
 
@@ -12,11 +15,12 @@
 #include "util/index_set/indexer.h"
 #include "util/table/table.h"
 
+// allele symbols and ploidy of the reference build (genotype/genotype.h:80-82, :39-41)
 #ifndef GENOTYPE_ALPHABET
-#define GENOTYPE_ALPHABET "ACGT"  // genotype/genotype.h:80-82
+#define GENOTYPE_ALPHABET "ACGT"
 #endif
 #ifndef MAX_ALLELE_COUNT
-#define MAX_ALLELE_COUNT 2  // genotype/genotype.h:39-41
+#define MAX_ALLELE_COUNT 2
 #endif
 
 namespace libgwaspp {
@@ -29,27 +33,32 @@ class GenoTable : public util::Table<DataBlock>,
 public:
     GenoTable(util::indexer *markers, util::indexer *individuals)
         : util::Table<DataBlock>(markers, individuals), beg(nullptr), end(nullptr), possible_genotypes_size(0) {}
+    virtual ~GenoTable() { delete[] beg; }
 
+    // ---- ingest: one cell, or one SNP row of text "AC<delim>AA<delim>..."
     virtual void addGenotype(int rIdx, int cIdx, const std::string &gt) = 0;
+    virtual void addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim) = 0;
     virtual void addGenotypeRow(int rIdx, std::string::const_iterator &it, std::string::const_iterator &it_end,
                                 char delim) = 0;
-    virtual void addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim) = 0;
 
+    // ---- genotype vocabulary: text <-> encoding (4*a1 + a2 over the alphabet, 0xFFFF = unknown)
     virtual ushort encodeGenotype(const std::string &gt) = 0;
     virtual const char *decodeGenotype(ushort encoded_gt) = 0;
     virtual bool isGenotypeHomozygous(ushort enc) = 0;
-
-    const char *getCallAt(uint marker_idx, uint individ_idx) { return decodeGenotype(getGenotypeAt(marker_idx, individ_idx)); }
-    DataBlock getGenotypeAt(uint marker_idx, uint individ_idx) { return (*this)((int)marker_idx, (int)individ_idx); }
-
     uint getPossibleGenotypeCount() const { return possible_genotypes_size; }
     virtual ushort *possible_genotypes_begin() const { return beg; }
     virtual ushort *possible_genotypes_end() const { return end; }
 
-    virtual ~GenoTable() { delete[] beg; }
+    // ---- one call, decoded
+    DataBlock getGenotypeAt(uint marker_idx, uint individ_idx) {
+        return (*this)(static_cast<int>(marker_idx), static_cast<int>(individ_idx));
+    }
+    const char *getCallAt(uint marker_idx, uint individ_idx) {
+        return decodeGenotype(getGenotypeAt(marker_idx, individ_idx));
+    }
 
 protected:
-    ushort *beg, *end;
+    ushort *beg, *end;  // the encodings a cell can hold
     uint possible_genotypes_size;
 };
 

@@ -1,70 +1,32 @@
-// genetics/genotype/single_marker_analyzable.h -- per-SNP operator API and its
-// caller-owned result holders (reference: genotype/single_marker_analyzable.h:
-// GenotypeDistribution :41-79, CaseControlGenotypeDistribution :81-127,
-// SingleMarkerAnalyzable :129-164).
+// genetics/genotype/single_marker_analyzable.h -- the per-SNP half of the table's operator API
+// (reference: genotype/single_marker_analyzable.h:129-164).  The result holders it fills live in
+// scan_results.h.
 #pragma once
 #include "genetics/analyzable/case_control_set.h"
 #include "genetics/genotype/case_control_selectable.h"
-#include "genetics/genotype/common_genotype.h"
+#include "genetics/genotype/scan_results.h"
 
 namespace libgwaspp {
 namespace genetics {
 
-class GenotypeDistribution {
-public:
-    GenotypeDistribution() { reset(); }
-    uint getCurrentIndex() { return current_rIdx; }
-    const frequency_table *getDistribution() { return &distribution; }
-    const header_table *getGenotypes() { return &genotypes; }
-    void setDistribution(const frequency_table &ft) { CopyFrequencyTable(distribution, ft); }
-    void reset() {
-        ResetFrequencyTable(distribution);
-        ResetHeaderTable(genotypes);
-        current_rIdx = (uint)-1;
-    }
-    virtual ~GenotypeDistribution() {}
-
-protected:
-    uint current_rIdx;
-    frequency_table distribution;
-    header_table genotypes;
-};
-
-class CaseControlGenotypeDistribution {
-public:
-    CaseControlGenotypeDistribution() { reset(); }
-    uint getCurrentIndex() { return current_rIdx; }
-    const frequency_table *getCaseDistribution() { return &case_dist; }
-    const frequency_table *getControlDistribution() { return &control_dist; }
-    const header_table *getGenotypes() { return &genotypes; }
-    void setCaseDistribution(const frequency_table &ft) { CopyFrequencyTable(case_dist, ft); }
-    void setControlDistribution(const frequency_table &ft) { CopyFrequencyTable(control_dist, ft); }
-    void reset() {
-        ResetFrequencyTable(case_dist);
-        ResetFrequencyTable(control_dist);
-        ResetHeaderTable(genotypes);
-        current_rIdx = (uint)-1;
-    }
-    virtual ~CaseControlGenotypeDistribution() {}
-
-protected:
-    uint current_rIdx;
-    frequency_table case_dist, control_dist;
-    header_table genotypes;
-};
-
 class SingleMarkerAnalyzable : public virtual CaseControlSelectable {
 public:
-    virtual void selectMarker(uint rIdx) = 0;
+    virtual ~SingleMarkerAnalyzable() {}
+
+    // counts of one SNP over every sample
     virtual void getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist) = 0;
-    // masks applied inline
+
+    // counts of one SNP split by phenotype:
+    //   with the masks of `ccs` applied on the fly ...
     virtual void getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs,
                                                     CaseControlGenotypeDistribution &ccgd) = 0;
-    // after selectCaseControl()
+    //   ... or after selectCaseControl(), optionally with the SNP's marginal information
     virtual void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd) = 0;
     virtual void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd,
                                                     marginal_information &m) = 0;
-    virtual ~SingleMarkerAnalyzable() {}
+
+    // legacy look-up-table path of the older tables (assert(false) in the 2-bit stream table)
+    virtual void selectMarker(uint rIdx) = 0;
 };
 
 }  // namespace genetics
