@@ -1,20 +1,26 @@
 // gw_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the per-SNP association
 // scan.  Hand-written HIP; no MFMA: this is a popcount / HBM-bandwidth
 // problem (about 0.4 integer ops per byte), so everything here is about
-// 16-byte-per-lane coalesced streaming, enough loads in flight per CU, and
-// keeping the phenotype masks out of the HBM stream.
+// 16-byte-per-lane coalesced streaming, the right number of bytes in flight per
+// CU, and keeping the phenotype masks out of the HBM stream.
 //
 // Reference algorithm restated by each kernel (paths relative to
 // /root/reference/src/libgwaspp/):
-//   k_scan_cc    getCaseControlGenotypeDistribution(r, ccs, ccgd)
-//                genotype/compressed_genotype_table5.cpp:609-657, inside the
-//                SNP loop of inline_cc_maf, algorithms/maf_func.cpp:292-316,
-//                + MinorAlleleFrequency, algorithms/maf_func.h:46-54
-//   k_scan_dist  getGenotypeDistribution, table5.cpp:577-607
-//   k_pair*      getContingencyTable / getCaseControlContingencyTable,
-//                table5.cpp:749-800 / 806-895
-//   k_restride*  the row packings of table5.cpp:277-365 / table3.cpp:260-325
-//   k_simulate*  data/simulate_data.cpp:150-235
+//   k_scan_cc        getCaseControlGenotypeDistribution(r, ccs, ccgd)
+//   k_scan_cc_pipe   genotype/compressed_genotype_table5.cpp:609-657, inside the
+//   k_scan_cc_compl  SNP loop of inline_cc_maf, algorithms/maf_func.cpp:292-316,
+//                    + MinorAlleleFrequency, algorithms/maf_func.h:46-54, + the
+//                    build-defined HWE / chi-square statistics.
+//                    Three forms of the same scan: row-at-a-time; continuous
+//                    stream (inline-asm loads, counted waits; the c3 default);
+//                    single mask for complementary phenotypes (N up to 1.3 M).
+//   k_scan_dist      getGenotypeDistribution, table5.cpp:577-607
+//   k_pair           getContingencyTable / getCaseControlContingencyTable for a
+//                    list of SNP pairs, table5.cpp:749-800 / 806-895
+//   k_restride_*     the row packings of table5.cpp:277-365 / table3.cpp:260-325
+//   k_simulate*      data/simulate_data.cpp:150-235
+//   k_stream_probe   the scan's traversal with the arithmetic removed
+// (the all-pairs BOOST path is in gw_boost.hip)
 #include "gw_kernels.h"
 
 namespace gw {
