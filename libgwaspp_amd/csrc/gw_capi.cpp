@@ -33,9 +33,11 @@ int fail(int code, const char *fmt, ...) {
 #define GW_HIP(expr)                                                                       \
     do {                                                                                   \
         hipError_t e__ = (expr);                                                           \
-        if (e__ != hipSuccess)                                                             \
+        if (e__ != hipSuccess) {                                                           \
+            (void)hipGetLastError(); /* reset the runtime's sticky "last error" */         \
             return fail(e__ == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "%s: %s", #expr, \
                         hipGetErrorString(e__));                                           \
+        }                                                                                  \
     } while (0)
 
 constexpr size_t kStagingBytes = 64u << 20;
@@ -278,9 +280,11 @@ int gw_table_create(int device, uint32_t n_samples, uint64_t n_snps, gw_table **
 #define GW_HIP_T(expr)                                                                       \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
+        if (e__ != hipSuccess) {                                                             \
+            (void)hipGetLastError();                                                         \
             return bail(fail(e__ == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "%s: %s",   \
                              #expr, hipGetErrorString(e__)));                                \
+        }                                                                                    \
     } while (0)
     GW_HIP_T(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     GW_HIP_T(hipEventCreate(&t->ev_start));

@@ -368,3 +368,61 @@ def test_pitched_row_buffers(oracle, layout, lname):
         assert np.array_equal(back[:, :table.shape[1]], table) and not back[:, table.shape[1]:].any()
         with pytest.raises(gw.GwError):   # a stride shorter than a row
             t.upload_rows(0, table[:, :-1].copy(), layout)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_configurations(oracle, seed):
+    """Random table sizes, packings, masks (complementary, overlapping, sparse), missing rates,
+    kernel shapes and SNP sub-ranges against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 40_000)]))
+    m = int(rng.integers(1, 150))
+    codes = _random_codes(rng, m, n, p_missing=float(rng.choice([0.0, 0.01, 0.3])))
+    lname = str(rng.choice(["stream", "block"]))
+    table = oracle.pack_codes(codes, lname)
+    ts = table if lname == "stream" else oracle.pack_codes(codes, "stream")
+    kind = int(rng.integers(0, 4))
+    u = rng.random(n)
+    if kind == 0:      # every sample a case or a control
+        cases, ctrls = np.flatnonzero(u < 0.5), np.flatnonzero(u >= 0.5)
+    elif kind == 1:    # some in neither
+        cases, ctrls = np.flatnonzero(u < 0.3), np.flatnonzero(u > 0.6)
+    elif kind == 2:    # overlap
+        cases, ctrls = np.flatnonzero(u < 0.6), np.flatnonzero(u > 0.4)
+    else:              # sparse
+        cases, ctrls = np.flatnonzero(u < 0.02), np.flatnonzero(u > 0.97)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    gs = oracle.geometry_stream(n)
+    want_c, want_s = oracle.scan_stream_cc(ts, gs, cs, ct, nc, nt)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, table, gw.LAYOUT_STREAM if lname == "stream" else gw.LAYOUT_BLOCK)
+        t.set_case_control(cs, ct, nc, nt)
+        t.set_option(capi.OPT_UNROLL, int(rng.choice([0, 1, 2, 4, 8])))
+        t.set_option(capi.OPT_BLOCK_THREADS, int(rng.choice([0, 256, 512, 1024])))
+        t.set_option(capi.OPT_BLOCKS_PER_CU, int(rng.integers(0, 5)))
+        t.set_option(capi.OPT_MASK_IN_LDS, int(rng.choice([-1, 0, 1])))
+        t.set_option(capi.OPT_NONTEMPORAL, int(rng.integers(0, 2)))
+        t.set_option(capi.OPT_PIPELINE, int(rng.choice([-1, 0, 1])))
+        t.set_option(capi.OPT_COMPLEMENT, int(rng.integers(0, 3)))
+        b = int(rng.integers(0, m))
+        k = int(rng.integers(0, m - b + 1))
+        counts, stats = t.scan_case_control(b, k)
+        assert np.array_equal(counts, want_c[b:b + k])
+        _assert_stats(stats, want_s[b:b + k])
+        dist = t.scan_distribution(b, k)
+        for r in range(b, b + k, max(1, k // 5)):
+            aa, ab, bb, _ = oracle.stream_dist(ts[r], gs)
+            assert tuple(int(v) for v in dist[r - b]) == (aa, ab, bb, n - aa - ab - bb)
+
+
+def test_allocation_failure_is_reported_not_fatal():
+    """A table that cannot fit in HBM: GW_E_NOMEM with a message, and the device stays usable."""
+    info = capi.device_info(0)
+    n = 500_000
+    too_many = int(info.hbm_bytes / (n / 4.0) * 1.5)
+    with pytest.raises(gw.GwError) as e:
+        gw.GwTable(n, too_many)
+    assert e.value.code == -3, str(e.value)
+    with gw.GwTable(1000, 10) as t:      # still works afterwards
+        assert t.scan_distribution().shape == (10, 4)
