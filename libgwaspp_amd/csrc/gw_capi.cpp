@@ -763,7 +763,11 @@ int ensure_selected(gw_table *t) {
     if (e == hipSuccess) e = gw::launch_select_cc(t->tv, d_src, wc, wt, t->d_cc, stride_w, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     (void)hipFree(d_src);
-    if (e != hipSuccess) return fail(GW_E_HIP, "selectCaseControl on the device: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "selectCaseControl on the device: %s",
+                    hipGetErrorString(e));
+    }
     t->wc = wc;
     t->wt = wt;
     t->cc_stride_w = stride_w;
@@ -848,7 +852,10 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     if (e == hipSuccess && dense && d_dense) e = hipMemcpy(dense, d_dense, n_a * n_b * sizeof(double), hipMemcpyDeviceToHost);
     if (d_hits) (void)hipFree(d_hits);
     if (d_dense) (void)hipFree(d_dense);
-    if (e != hipSuccess) return fail(GW_E_HIP, "BOOST pre-screen: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "BOOST pre-screen: %s", hipGetErrorString(e));
+    }
     if (n_hits) *n_hits = tally[0];
     if (n_pairs) *n_pairs = tally[1];
     if (vmax) *vmax = tally[1] ? from_ordered(tally[2]) : 0.0;
