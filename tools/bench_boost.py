@@ -2,6 +2,7 @@
 """Pairs/s of the BOOST / KSA pre-screen (BASELINE.json configs[4]-shaped:
 all pairs of M SNPs, N samples) on one GPU.
     python tools/bench_boost.py --snps 100000 --samples 10000
+(the CPU baseline and the parity check of this path live in `bench.py --workload c5`)
 """
 import argparse
 import json
@@ -18,7 +19,6 @@ ap.add_argument("--snps", type=int, default=100_000)
 ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--missing-q16", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--cpu-pairs", type=int, default=0, help="time the oracle on the first K SNPs' pairs")
 args = ap.parse_args()
 
 m, n = args.snps, args.samples
@@ -39,14 +39,5 @@ out = {"metric": "SNP pairs/s, BOOST KSA pre-screen", "value": n_pairs / best, "
        "hits_over_30": n_hits, "max_measure": vmax, "min_measure": vmin,
        "popcount_path": "4 corners + margins" if args.missing_q16 == 0 else "9 cells",
        "and_popc_per_s": n_pairs / best * (n / 32.0) * (4 if args.missing_q16 == 0 else 9)}
-if args.cpu_pairs:
-    from oracle import oracle
-    k = args.cpu_pairs
-    rows = t.download_rows(0, k)
-    cs, ct, nc, nt = t.get_case_control()
-    t0 = time.perf_counter()
-    oracle.boost_all_pairs(rows, oracle.geometry_stream(n), cs, ct, nc, nt)
-    dt = time.perf_counter() - t0
-    out["cpu_oracle_pairs_per_s_1core"] = (k * (k - 1) // 2) / dt
 print(json.dumps(out))
 t.close()
