@@ -481,6 +481,27 @@ void gwo_stream_cc_contingency(const uint16_t *ra, const uint16_t *rb, const gwo
     }
 }
 
+/* table3.cpp:733-849; AddToContingency2BitBlock, compressed_genotype_table3.h:110-115 */
+void gwo_block_cc_contingency(const uint16_t *ra, const uint16_t *rb, const gwo_geom *g, const uint16_t *cs,
+                              const uint16_t *ct, uint32_t out_case[16], uint32_t out_ctrl[16]) {
+    pthread_once(&g_pop_once, build_pop16);
+    memset(out_case, 0, 16 * sizeof(uint32_t));
+    memset(out_ctrl, 0, 16 * sizeof(uint32_t));
+    for (uint32_t w = 0; w < g->words; ++w) {
+        const uint64_t va = ld64(ra + 1 + 4 * w), vb = ld64(rb + 1 + 4 * w);
+        for (int grp = 0; grp < 2; ++grp) {
+            const uint64_t m = ld64((grp ? ct : cs) + 4 * w);
+            if (!m) continue; /* :757, :779 */
+            uint32_t *out = grp ? out_ctrl : out_case;
+            uint64_t a[3], b[3];
+            decode_block(va & m, &a[0], &a[1], &a[2]);
+            decode_block(vb & m, &b[0], &b[1], &b[2]);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) out[4 * i + j] += fold_count(a[i] & b[j]);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* arithmetic on the counts                                                  */
 /* ------------------------------------------------------------------------ */

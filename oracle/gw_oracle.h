@@ -138,6 +138,18 @@ void gwo_stream_cc_contingency(const uint16_t *row_a, const uint16_t *row_b, con
                                const uint16_t *case_stream, const uint16_t *ctrl_stream,
                                uint32_t out_case[16], uint32_t out_ctrl[16]);
 
+/* ---- pairwise contingency, block layout ----
+ * getCaseControlContingencyTable(i, j, ccs, ccct) of the 2-bit block table
+ * (table3.cpp:733-849): the nine joint genotype cells only, the xx row/column
+ * stays zero.  (CGT3's plain getContingencyTable(i,j,ct) starts four blocks
+ * into the row -- quirk Q4, table3.cpp:671-672 -- and is not restated.)
+ * Together with gwo_stream_cc_contingency this is the cross-compression-level
+ * check that scripts/perl/contin_output_comparer.pl performs on --epi-debug
+ * dumps. */
+void gwo_block_cc_contingency(const uint16_t *row_a, const uint16_t *row_b, const gwo_geom *g,
+                              const uint16_t *case_block, const uint16_t *ctrl_block,
+                              uint32_t out_case[16], uint32_t out_ctrl[16]);
+
 /* ---- arithmetic on the counts ---- */
 /* MinorAlleleFrequency (algorithms/maf_func.h:46-54), quirk Q5 kept. */
 void gwo_minor_allele_frequency(const gwo_freq *ft, double *tot, double *maf);

@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L.gwo_block_cc_dist.argtypes = [u16p, gp, u16p, u16p, fp, fp]
         L.gwo_stream_contingency.argtypes = [u16p, u16p, gp, u32p]
         L.gwo_stream_cc_contingency.argtypes = [u16p, u16p, gp, u16p, u16p, u32p, u32p]
+        L.gwo_block_cc_contingency.argtypes = [u16p, u16p, gp, u16p, u16p, u32p, u32p]
         L.gwo_minor_allele_frequency.argtypes = [fp, f64p, f64p]
         L.gwo_marginal_information.argtypes = [fp, fp, C.c_uint32, C.POINTER(Marginal)]
         L.gwo_marginal_information.restype = C.c_int
@@ -255,6 +256,13 @@ def stream_cc_contingency(row_a, row_b, g, case_stream, ctrl_stream):
     a, b = np.zeros(16, dtype=np.uint32), np.zeros(16, dtype=np.uint32)
     lib().gwo_stream_cc_contingency(_p16(row_a), _p16(row_b), C.byref(g), _p16(case_stream),
                                     _p16(ctrl_stream), _p32(a), _p32(b))
+    return a, b
+
+
+def block_cc_contingency(row_a, row_b, g, case_block, ctrl_block):
+    a, b = np.zeros(16, dtype=np.uint32), np.zeros(16, dtype=np.uint32)
+    lib().gwo_block_cc_contingency(_p16(row_a), _p16(row_b), C.byref(g), _p16(case_block), _p16(ctrl_block),
+                                   _p32(a), _p32(b))
     return a, b
 
 

@@ -164,3 +164,33 @@ def test_packer_rejects_what_the_reference_asserts_on(oracle):
     t = oracle.pack_rows([b"AB\t00\tNN\tAA\t"], n)
     g = oracle.geometry_stream(n)
     assert oracle.stream_dist(t[0], g)[:3] == (1, 0, 0)
+
+
+@pytest.mark.parametrize("name", [s for s in CC if _n_of(s) <= 1000])
+def test_pair_tables_agree_across_compression_levels(oracle, name):
+    """What scripts/perl/contin_output_comparer.pl checks on two --epi-debug dumps: the
+    case/control pair tables of the 2-bit block table (table3.cpp:733-849) and of the 2-bit stream
+    table (table5.cpp:806-895) hold the same nine joint-genotype cells; and the cells add up to the
+    single-SNP counts the golden files give."""
+    n = _n_of(name)
+    lines = read_tped(name)
+    exp_case = read_dist(name, "case.dist")
+    cases, ctrls = read_tfam_status(name)
+    texts = [oracle.tped_genotype_text(ln) for ln in lines]
+    gs, gb = oracle.geometry_stream(n), oracle.geometry_block(n)
+    ts, tb = oracle.pack_rows(texts, n, "stream"), oracle.pack_rows(texts, n, "block")
+    bm_c, sm_c, nc = oracle.ccs_masks(cases, n)
+    bm_t, sm_t, nt = oracle.ccs_masks(ctrls, n)
+    m = len(lines)
+    for i in range(m):
+        for j in range(i + 1, m):
+            sc, st = oracle.stream_cc_contingency(ts[i], ts[j], gs, sm_c, sm_t)
+            bc, bt = oracle.block_cc_contingency(tb[i], tb[j], gb, bm_c, bm_t)
+            nine = [4 * a + b for a in range(3) for b in range(3)]
+            assert np.array_equal(sc[nine], bc[nine]) and np.array_equal(st[nine], bt[nine])
+            assert not bc[[3, 7, 11, 12, 13, 14, 15]].any()        # CGT3 leaves the xx margins at zero
+            # row sums of the case table = marker i's case counts (no missing calls in these files)
+            ei = expected_in_table_space(exp_case[i], lines[i])
+            assert tuple(int(sc[4 * a:4 * a + 3].sum()) for a in range(3)) == ei[:3]
+            # the stream table sends every non-member and pad bit to xx_xx (quirk Q7)
+            assert int(sc.sum()) == gs.words * 64 and int(sc[15]) == gs.words * 64 - nc
