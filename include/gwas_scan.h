@@ -210,7 +210,11 @@ int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_
  * :390,482) are listed.  The block form lets callers shard the pair space.
  * hits[max_hits] receives at most max_hits entries in no particular order;
  * *n_hits is the total found (may exceed max_hits), *n_pairs the pairs
- * evaluated, *max_measure / *min_measure the extremes (:472-480). */
+ * evaluated, *max_measure / *min_measure the extremes (:472-480; the
+ * reference tracks but never prints them).  Any of the four may be NULL; with
+ * both extremes NULL the screen may skip the FP64 measure of pairs that a
+ * single-precision bound proves to be below the threshold
+ * (GW_OPT_BOOST_PREFILTER) -- same hit list, ~1.5x faster at N = 10 k. */
 typedef struct gw_boost_hit {
     uint32_t snp_a, snp_b;
     double measure;
@@ -252,6 +256,11 @@ typedef enum gw_option {
                                 can stage one mask in LDS and take controls = all - cases: 0 never,
                                 1 (default) only where two masks do not fit the LDS (650 k < N <= 1.3 M),
                                 2 whenever possible; get returns whether the current masks/shape use it */
+    GW_OPT_BOOST_PREFILTER = 8, /* gw_boost_screen without max_measure / min_measure: 1 (default) decide each
+                                pair first by a single-precision bound of the measure and evaluate the FP64
+                                measure only where bound >= threshold - slack (slack = 2n * 1e-4 + 0.05;
+                                the hit list is the same, listed measures are the FP64 ones); 0 never;
+                                2 diagnostic: gw_boost_measures returns the bound instead of the measure */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

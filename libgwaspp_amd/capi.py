@@ -24,6 +24,7 @@ N_COUNTS = 8
 N_STATS = 8
 
 OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS, OPT_PIPELINE, OPT_COMPLEMENT = 1, 2, 3, 4, 5, 6, 7
+OPT_BOOST_PREFILTER = 8
 
 
 class GwError(RuntimeError):
@@ -303,15 +304,19 @@ class GwTable:
 
     # ---- BOOST / KSA pre-screen
     def boost_screen(self, a_begin: int, n_a: int, b_begin: int, n_b: int, threshold: float = 30.0,
-                     max_hits: int = 1 << 20):
-        """-> (hits structured array [snp_a, snp_b, measure], n_hits, n_pairs, max, min)"""
+                     max_hits: int = 1 << 20, extremes: bool = True):
+        """-> (hits structured array [snp_a, snp_b, measure], n_hits, n_pairs, max, min);
+        extremes=False passes NULL for max/min (they come back as None): the screen may then use its
+        single-precision bound first (GW_OPT_BOOST_PREFILTER)."""
         dt = np.dtype([("snp_a", np.uint32), ("snp_b", np.uint32), ("measure", np.float64)])
         hits = np.zeros(max_hits, dtype=dt)
         nh, npairs = C.c_uint64(0), C.c_uint64(0)
         vmax, vmin = C.c_double(0), C.c_double(0)
         _check(self._L.gw_boost_screen(self._h, a_begin, n_a, b_begin, n_b, threshold, hits.ctypes.data, max_hits,
-                                       C.byref(nh), C.byref(npairs), C.byref(vmax), C.byref(vmin)))
-        return hits[:min(nh.value, max_hits)], nh.value, npairs.value, vmax.value, vmin.value
+                                       C.byref(nh), C.byref(npairs), C.byref(vmax) if extremes else None,
+                                       C.byref(vmin) if extremes else None))
+        return (hits[:min(nh.value, max_hits)], nh.value, npairs.value, vmax.value if extremes else None,
+                vmin.value if extremes else None)
 
     def boost_measures(self, a_begin: int, n_a: int, b_begin: int, n_b: int) -> np.ndarray:
         out = np.zeros((n_a, n_b), dtype=np.float64)

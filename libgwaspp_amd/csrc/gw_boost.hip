@@ -75,7 +75,8 @@ hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint
 // marginal_information per SNP from the scan's counts
 // (common_genotype_func.cpp:173-219; unwritten entries are zero here)
 // ---------------------------------------------------------------------------
-__global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *mar) {
+__global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *mar,
+                          SnpMarginF *marf) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const uint32_t *c = counts + (size_t)r * 8u;
@@ -114,13 +115,29 @@ __global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_in
         }
     }
     mar[r] = m;
+    // single-precision factors of the pre-screen's bound (not part of the reference's record)
+    SnpMarginF f;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const double n_grp = (double)(grp == 0 ? n_cases : n_ctrls);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const uint32_t k = grp == 0 ? m.cases[g] : m.ctrls[g];
+            const double mg = (double)m.margins[g];
+            f.qb[3 * grp + g] = k ? (float)(mg * n_grp / (double)k) : 0.0f;
+            f.qa[3 * grp + g] = k ? (float)(mg / (double)k) : 0.0f;
+            f.rb[3 * grp + g] = k ? (float)(m.pbc[4 * grp + g] / mg) : 0.0f;
+            f.pa[3 * grp + g] = (float)m.pca[4 * grp + g];
+        }
+    }
+    marf[r] = f;
 }
 
 hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *d_mar,
-                          hipStream_t stream) {
+                          SnpMarginF *d_marf, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     hipLaunchKernelGGL(k_margins, dim3((n_rows + 255u) / 256u), dim3(256), 0, stream, d_counts, n_rows,
-                       n_individs, d_mar);
+                       n_individs, d_mar, d_marf);
     return hipGetLastError();
 }
 
@@ -189,6 +206,32 @@ __device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const u
     return (im + log(tao)) * n * 2.0;
 }
 
+// The same quantity in single precision, arranged for one v_log_f32 per cell and group:
+//   measure = 2 * sum_cells [ x ln(r_case) + y ln(r_ctrl) ] + 2 n ln(tao),
+//   r = (k/n) / (pab * pbc * pca) = k / (x+y) / n * qb[b] * qa[a]
+// Its error against the FP64 measure stays far below the slack the caller subtracts from the
+// threshold (tests/test_gpu_boost.py measures it), so "bound < threshold - slack" proves that the
+// pair cannot pass; anything else (including NaN) is decided by the FP64 measure.
+__device__ __forceinline__ float boost_bound(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                             const SnpMarginF &f1, const SnpMarginF &f2, float n, float inv_n) {
+    float s = 0.0f, tao = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t x = ca[3 * a + b], y = co[3 * a + b];
+            const float fx = (float)x, fy = (float)y, fs = (float)(x + y);
+            const float rs = __builtin_amdgcn_rcpf(fs) * inv_n;
+            tao += fs * (f2.rb[b] * f1.pa[a] + f2.rb[3 + b] * f1.pa[3 + a]);
+            const float lx = fx * __log2f(fx * rs * (f2.qb[b] * f1.qa[a]));
+            const float ly = fy * __log2f(fy * rs * (f2.qb[3 + b] * f1.qa[3 + a]));
+            s += x ? lx : 0.0f;
+            s += y ? ly : 0.0f;
+        }
+    }
+    return 1.3862943611198906f * (s + n * __log2f(tao));  // 2 ln 2
+}
+
 struct BoostArgs {
     const uint32_t *cc;
     uint64_t cc_stride_w;
@@ -202,6 +245,8 @@ struct BoostArgs {
     unsigned long long max_hits;
     unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
     double *dense;              // n_a x n_b, or null
+    const SnpMarginF *marf;     // PRE only
+    float bound_threshold;      // PRE: pairs whose FP32 bound is below this are not hits
 };
 
 // One workgroup = a TA x TB tile of SNP pairs; 256 threads, each owns a 2 x 2
@@ -211,7 +256,8 @@ struct BoostArgs {
 // joint counts of its four pairs with AND + v_bcnt.
 //   FAST = the reference's no-missing shortcut (table5.cpp:1066-1143): only
 //   the four homozygote corners are counted, the rest follows from the margins.
-template <bool FAST>
+//   PRE = the FP32 bound decides first; the FP64 measure runs only for pairs it cannot rule out.
+template <bool FAST, bool PRE>
 __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
     constexpr int NV = FAST ? 2 : 3;   // class vectors per row
     constexpr int NC = FAST ? 4 : 9;   // joint counts per pair and group
@@ -235,35 +281,48 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) cnt[g][p][c] = 0;
 
+    // Staging: thread t carries words 4q .. 4q+3 (q = t & 7) of A-row t >> 3 and of B-row t >> 3, both
+    // planes, as four 16-byte loads.  The loads of chunk k+1 are issued before chunk k is consumed and
+    // land in registers while the popcounts run; rows past the block end repeat its last row (their
+    // pairs are never reported) and the planes are zero-padded to whole chunks (gw_capi.cpp), so no
+    // load is conditional.
+    static_assert(TA == 32 && TB == 32 && CH == 32, "staging map: 256 threads x (A row, B row) x 4 words");
+    const uint32_t srow = t >> 3, sq = t & 7u;
+    const uint32_t *rowA = a.cc + (uint64_t)min(a0 + srow, a_end - 1u) * a.cc_stride_w + 4u * sq;
+    const uint32_t *rowB = a.cc + (uint64_t)min(b0 + srow, b_end - 1u) * a.cc_stride_w + 4u * sq;
+    u32x4 nA0, nA1, nB0, nB1;  // next chunk: plane 0 / plane 1 of the A row and of the B row
+    auto fetch = [&](uint32_t off, uint32_t wn, uint32_t w0) {
+        nA0 = *reinterpret_cast<const u32x4 *>(rowA + off + w0);
+        nA1 = *reinterpret_cast<const u32x4 *>(rowA + off + wn + w0);
+        nB0 = *reinterpret_cast<const u32x4 *>(rowB + off + w0);
+        nB1 = *reinterpret_cast<const u32x4 *>(rowB + off + wn + w0);
+    };
+    auto stash = [&]() {  // class vectors derived on the way in
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t pa0 = nA0[e], pa1 = nA1[e], pb0 = nB0[e], pb1 = nB1[e];
+            sA[0][srow][4u * sq + e] = pa0 & ~pa1;       // aa
+            sA[NV - 1][srow][4u * sq + e] = pa0 & pa1;   // bb
+            sB[0][srow][4u * sq + e] = pb0 & ~pb1;
+            sB[NV - 1][srow][4u * sq + e] = pb0 & pb1;
+            if (!FAST) {
+                sA[1][srow][4u * sq + e] = pa1 & ~pa0;   // ab
+                sB[1][srow][4u * sq + e] = pb1 & ~pb0;
+            }
+        }
+    };
+    fetch(0u, a.wc, 0u);
+
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t wn = g == 0 ? a.wc : a.wt;              // words per plane of this group
+        const uint32_t wn = g == 0 ? a.wc : a.wt;              // words per plane of this group (x CH)
         const uint32_t off = g == 0 ? 0u : 2u * a.wc;          // plane 0 of the group inside the row
         for (uint32_t w0 = 0; w0 < wn; w0 += CH) {
             __syncthreads();
-            // stage: (TA + TB) rows x CH words, class vectors derived on the way in
-            for (uint32_t idx = t; idx < (uint32_t)(TA + TB) * CH; idx += 256u) {
-                const uint32_t row = idx / CH, w = idx % CH;
-                const bool isB = row >= (uint32_t)TA;
-                const uint32_t snp = isB ? b0 + (row - TA) : a0 + row;
-                uint32_t p0 = 0, p1 = 0;
-                if (snp < (isB ? b_end : a_end) && w0 + w < wn) {
-                    const uint32_t *src = a.cc + (uint64_t)snp * a.cc_stride_w + off + w0 + w;
-                    p0 = src[0];
-                    p1 = src[wn];
-                }
-                const uint32_t bb = p0 & p1, aa = p0 & ~p1, ab = p1 & ~p0;
-                if (isB) {
-                    sB[0][row - TA][w] = aa;
-                    sB[NV - 1][row - TA][w] = bb;
-                    if (!FAST) sB[1][row - TA][w] = ab;
-                } else {
-                    sA[0][row][w] = aa;
-                    sA[NV - 1][row][w] = bb;
-                    if (!FAST) sA[1][row][w] = ab;
-                }
-            }
+            stash();
             __syncthreads();
+            if (w0 + CH < wn) fetch(off, wn, w0 + CH);
+            else if (g == 0) fetch(2u * a.wc, a.wt, 0u);
 #pragma unroll 4
             for (int w = 0; w < CH; ++w) {
                 uint32_t x[2][NV], y[2][NV];
@@ -322,10 +381,21 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
                         co[c] = cnt[1][2 * pi + pj][c];
                     }
                 }
-                measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
                 ++n_eval;
-                vmax = fmax(vmax, measure);
-                vmin = fmin(vmin, measure);
+                if (PRE) {
+                    const float bound = boost_bound(ca, co, a.marf[i], a.marf[j], (float)a.n_individs,
+                                                    1.0f / (float)a.n_individs);
+                    if (a.dense) {  // diagnostic form: the bound itself
+                        a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
+                        continue;
+                    }
+                    if (bound < a.bound_threshold) continue;  // false for NaN
+                }
+                measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+                if (!PRE) {
+                    vmax = fmax(vmax, measure);
+                    vmin = fmin(vmin, measure);
+                }
                 if (measure > a.threshold) {  // :482-484
                     const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
                     if (slot < a.max_hits) {
@@ -349,8 +419,10 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
     }
     if ((t & 63u) == 0 && n_eval) {
         atomicAdd(&a.tally[1], n_eval);
-        atomicMax(&a.tally[2], ordered(vmax));
-        atomicMin(&a.tally[3], ordered(vmin));
+        if (!PRE) {
+            atomicMax(&a.tally[2], ordered(vmax));
+            atomicMin(&a.tally[3], ordered(vmin));
+        }
     }
 }
 
@@ -359,16 +431,23 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
-                        bool fast, hipStream_t stream) {
+                        bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
+                        float bound_threshold) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
     a.a_begin = a_begin; a.n_a = n_a; a.b_begin = b_begin; a.n_b = n_b;
     a.n_individs = (int)n_individs; a.threshold = threshold;
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
+    a.marf = d_marf; a.bound_threshold = bound_threshold;
     const dim3 grid((n_b + TB - 1) / TB, (n_a + TA - 1) / TA);
-    if (fast) hipLaunchKernelGGL(k_boost<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_boost<false>, grid, dim3(256), 0, stream, a);
+    if (prefilter && d_marf) {
+        if (fast) hipLaunchKernelGGL((k_boost<true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost<false, true>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_boost<true, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost<false, false>), grid, dim3(256), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,6 +76,7 @@ struct gw_table {
     uint64_t cc_stride_w = 0;
     uint32_t wc = 0, wt = 0;
     gw::SnpMargin *d_mar = nullptr;
+    gw::SnpMarginF *d_marf = nullptr;
     double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
@@ -86,7 +88,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1;
 };
 
 namespace {
@@ -332,6 +334,7 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_misc) (void)hipFree(t->d_misc);
     if (t->d_cc) (void)hipFree(t->d_cc);
     if (t->d_mar) (void)hipFree(t->d_mar);
+    if (t->d_marf) (void)hipFree(t->d_marf);
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
     if (t->d_tally) (void)hipFree(t->d_tally);
@@ -743,19 +746,22 @@ int ensure_selected(gw_table *t) {
     std::vector<uint32_t> cases, ctrls;
     mask_members(t->h_case, t->geo.n_samples, nullptr, cases);
     mask_members(t->h_ctrl, t->geo.n_samples, &t->h_case, ctrls);
-    // dense planes padded to whole 16-byte units
-    const uint32_t wc = std::max<uint32_t>(4u, (uint32_t)((cases.size() + 127u) / 128u) * 4u);
-    const uint32_t wt = std::max<uint32_t>(4u, (uint32_t)((ctrls.size() + 127u) / 128u) * 4u);
+    // dense planes zero-padded to whole 32-word chunks (1024 members): k_boost stages a chunk at a time
+    // with unconditional 16-byte loads
+    const uint32_t wc = std::max<uint32_t>(32u, (uint32_t)((cases.size() + 1023u) / 1024u) * 32u);
+    const uint32_t wt = std::max<uint32_t>(32u, (uint32_t)((ctrls.size() + 1023u) / 1024u) * 32u);
     std::vector<uint32_t> src((size_t)(wc + wt) * 32u, 0xFFFFFFFFu);
     std::copy(cases.begin(), cases.end(), src.begin());
     std::copy(ctrls.begin(), ctrls.end(), src.begin() + (size_t)wc * 32u);
     const uint64_t stride_w = 2ull * (wc + wt);
     if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
     if (t->d_mar) { GW_HIP(hipFree(t->d_mar)); t->d_mar = nullptr; }
+    if (t->d_marf) { GW_HIP(hipFree(t->d_marf)); t->d_marf = nullptr; }
     if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long)));
     if (m) {
         GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
         GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
+        GW_HIP(hipMalloc((void **)&t->d_marf, m * sizeof(gw::SnpMarginF)));
     }
     uint32_t *d_src = nullptr;
     GW_HIP(hipMalloc((void **)&d_src, src.size() * sizeof(uint32_t)));
@@ -794,7 +800,7 @@ int ensure_selected(gw_table *t) {
         }
         if (rc) return rc;
         GW_HIP(gw::launch_margins(t->d_scratch32, (uint32_t)m, (uint32_t)(cases.size() + ctrls.size()), t->d_mar,
-                                  t->stream));
+                                  t->d_marf, t->stream));
         GW_HIP(hipStreamSynchronize(t->stream));
     }
     t->sel_individs = (uint32_t)(cases.size() + ctrls.size());
@@ -838,10 +844,22 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         e = hipMalloc((void **)&d_dense, n_a * n_b * sizeof(double));
         if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0xFF, n_a * n_b * sizeof(double), t->stream);  // NaN
     }
+    // FP32 bound first where nobody asked for the extremes: a pair is dropped without its FP64 measure
+    // only if bound < threshold - slack, slack = 2n * 1e-4 + 0.05 (the bound's error grows with n; see
+    // boost_bound and tests/test_gpu_boost.py, which measures it).  Option 2 = diagnostic: the dense
+    // form returns the bound instead of the measure.
+    const bool diag = dense && t->opt_prefilter == 2;
+    const bool pre = diag || (!dense && !vmax && !vmin && t->opt_prefilter != 0);
+    float bound_thr = 0.0f;
+    if (pre && !diag) {
+        const double cut = threshold - (2.0 * (double)t->sel_individs * 1.0e-4 + 0.05);
+        bound_thr = (float)cut;
+        if (!((double)bound_thr <= cut)) bound_thr = std::nextafter(bound_thr, -INFINITY);  // round down; NaN stays NaN
+    }
     if (e == hipSuccess)
         e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
                              (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
-                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream);
+                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -986,6 +1004,10 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "complement must be 0 (never), 1 (auto) or 2 (whenever possible)");
         t->opt_complement = (int)v;
         return GW_OK;
+    case GW_OPT_BOOST_PREFILTER:
+        if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
+        t->opt_prefilter = (int)v;
+        return GW_OK;
     default:
         return fail(GW_E_INVALID, "unknown option %d", option);
     }
@@ -1002,6 +1024,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BLOCK_THREADS: *v = sh.block_threads; return GW_OK;
     case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
+    case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }
 }

@@ -87,6 +87,14 @@ struct SnpMargin {
     double pbc[8];  // P(genotype | status): cases[4], controls[4]
     double pca[8];  // P(status | genotype)
 };
+// single-precision companions of a SnpMargin for the pre-screen's FP32 bound (k_boost<.., true>):
+// index = 3 * group + genotype, group 0 = cases, 1 = controls; zero where the count is zero
+struct SnpMarginF {
+    float qb[6];  // margins[g] * n_group / group[g]   = 1 / (P(g | status) / margins[g])
+    float qa[6];  // margins[g] / group[g]             = 1 / P(status | g)
+    float rb[6];  // P(g | status) / margins[g]
+    float pa[6];  // P(status | g)
+};
 struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
     uint32_t snp_a, snp_b;
     double measure;
@@ -96,7 +104,7 @@ struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
 hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
                             uint32_t *d_cc, uint64_t cc_stride_w, hipStream_t stream);
 hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *d_mar,
-                          hipStream_t stream);
+                          SnpMarginF *d_marf, hipStream_t stream);
 // BOOST pre-screen of the SNP block pair [a_begin,+n_a) x [b_begin,+n_b), pairs i < j
 // d_tally: [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
 hipError_t launch_boost_tables(uint32_t n_entries, uint32_t n_individs, double *d_frac, double *d_xlogx,
@@ -106,6 +114,9 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
-                        bool fast, hipStream_t stream);
+                        bool fast, hipStream_t stream,
+                        // FP32 bound first (prefilter), the FP64 measure only where it cannot rule a pair out;
+                        // no extremes in d_tally then; with d_dense the bound itself is written (diagnostic)
+                        const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f);
 
 }  // namespace gw

@@ -131,3 +131,69 @@ def test_boost_on_simulated_table_matches_oracle_and_finds_planted_pair(oracle):
         assert (7, 11) in {(int(h["snp_a"]), int(h["snp_b"])) for h in hits}
         assert n_hits == int((want[~np.isnan(want)] > 30.0).sum())
         assert vmax == pytest.approx(np.nanmax(want), rel=1e-10)
+
+
+def _prefilter_table(rng, n, m, p_missing, low_maf):
+    """Random table with a few strongly interacting pairs so that the measures span 0 .. thousands."""
+    q = rng.uniform(0.01, 0.12, size=(m, 1)) if low_maf else rng.uniform(0.05, 0.5, size=(m, 1))
+    a = rng.random((m, n)) < q
+    b = rng.random((m, n)) < q
+    codes = np.where(a & b, 3, np.where(a | b, 2, 1)).astype(np.uint8)
+    if p_missing:
+        codes[rng.random((m, n)) < p_missing] = 0
+    return codes
+
+
+@pytest.mark.parametrize("n,m,p_missing,low_maf", [(600, 48, 0.0, False), (600, 48, 0.05, True), (6000, 64, 0.0, True),
+                                                   (6000, 40, 0.02, False), (40_000, 40, 0.0, False),
+                                                   (40_000, 36, 0.0, True)])
+def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_maf):
+    """gw_boost_screen without extremes may rule pairs out by the single-precision bound
+    (GW_OPT_BOOST_PREFILTER): the hit list and its FP64 measures must not change, also for
+    thresholds that sit exactly on a pair's measure; and the bound's measured error must stay
+    well inside the slack the screen allows for it."""
+    rng = np.random.default_rng(n + 7 * m + int(low_maf))
+    codes = _prefilter_table(rng, n, m, p_missing, low_maf)
+    u = rng.random(n)
+    is_case = u < 0.45
+    # plant interactions of different strength: cases copy SNP i's genotype into SNP j
+    for (i, j, frac) in ((1, 5, 0.5), (2, 9, 0.15), (3, 11, 0.05), (4, 13, 0.02)):
+        flip = is_case & (rng.random(n) < frac)
+        codes[j, flip] = codes[i, flip]
+    ts = oracle.pack_codes(codes, "stream")
+    cases = np.flatnonzero(is_case).astype(np.int32)
+    ctrls = np.flatnonzero(u >= 0.55).astype(np.int32)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        exact = t.boost_measures(0, m, 0, m)
+        finite = np.sort(exact[np.isfinite(exact)])
+        n_sel = nc + nt
+        slack = 2.0 * n_sel * 1e-4 + 0.05
+
+        # the bound itself (diagnostic form)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 2)
+        bound = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
+        both = np.isfinite(exact) & np.isfinite(bound)
+        assert both.sum() >= 0.9 * np.isfinite(exact).sum()
+        err = np.abs(bound[both] - exact[both])
+        # error budget: a quarter of the slack, plus 2e-6 relative for the planted (huge) measures
+        assert np.all(err <= slack / 4 + 2e-6 * np.abs(exact[both])), (err.max(), slack)
+
+        thresholds = [30.0, float(np.median(finite)), float(finite[int(0.9 * len(finite))]), float(finite[-1]),
+                      float(finite[-2]), float(finite[len(finite) // 3]), -1.0e9, 1.0e9]
+        thresholds += [float(v) for v in rng.choice(finite, size=6)]           # exactly on a measure
+        thresholds += [float(np.nextafter(v, -np.inf)) for v in rng.choice(finite, size=3)]
+        for thr in thresholds:
+            ref_hits, ref_n, ref_pairs, _, _ = t.boost_screen(0, m, 0, m, threshold=thr)           # all FP64
+            hits, n_hits, n_pairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
+            assert vmax is None and vmin is None
+            assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
+            assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
+        # switched off: still the same
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 0)
+        hits0, n0, *_ = t.boost_screen(0, m, 0, m, threshold=30.0, extremes=False)
+        assert n0 == int((finite > 30.0).sum())

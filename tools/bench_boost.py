@@ -29,13 +29,23 @@ t0 = time.perf_counter()
 t.boost_screen(0, min(m, 64), 0, min(m, 64))  # builds the compacted rows + margins
 prep = time.perf_counter() - t0
 best = None
-for _ in range(args.reps):
+for _ in range(args.reps):  # every pair's FP64 measure (extremes requested)
     t0 = time.perf_counter()
     hits, n_hits, n_pairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=30.0, max_hits=1 << 20)
     dt = time.perf_counter() - t0
     best = dt if best is None else min(best, dt)
+all_fp64 = best
+best = None
+for _ in range(args.reps):  # hits only: single-precision bound first (the default screen)
+    t0 = time.perf_counter()
+    hits2, n_hits2, n_pairs2, _, _ = t.boost_screen(0, m, 0, m, threshold=30.0, max_hits=1 << 20, extremes=False)
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+import numpy as np
+same = n_hits2 == n_hits and np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(hits2, order=["snp_a", "snp_b"]))
 out = {"metric": "SNP pairs/s, BOOST KSA pre-screen", "value": n_pairs / best, "unit": "pairs/s",
-       "n_snps": m, "n_samples": n, "pairs": n_pairs, "seconds": best, "prep_seconds": prep,
+       "n_snps": m, "n_samples": n, "pairs": n_pairs, "seconds": best, "seconds_every_measure_fp64": all_fp64,
+       "same_hit_list": bool(same), "prep_seconds": prep,
        "hits_over_30": n_hits, "max_measure": vmax, "min_measure": vmin,
        "popcount_path": "4 corners + margins" if args.missing_q16 == 0 else "9 cells",
        "and_popc_per_s": n_pairs / best * (n / 32.0) * (4 if args.missing_q16 == 0 else 9)}
