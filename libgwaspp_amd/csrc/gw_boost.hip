@@ -16,9 +16,20 @@
 // from LDS): 9 (or 4) AND+popcount per 32 samples per pair, then ~20 FP64
 // logarithms per pair.  Still no MFMA: AND-popcount has no matrix-core form
 // on CDNA4 short of expanding every bit to a 4-bit element.
+#include <type_traits>
+
 #include "gw_kernels.h"
 
 namespace gw {
+
+// compile-time loop: the body sees its index as a constant
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // selectCaseControl: gather the members' bits into dense planes.
@@ -426,13 +437,271 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Matrix-core form of the same tile (tables without a missing call).
+//
+// The four counted corners of a pair are dot products of 0/1 class vectors over
+// the samples of a group -- a binary GEMM, and unlike the per-SNP scan it re-uses
+// every row M times, so it is compute- not HBM-bound.  v_bcnt_u32_b32 issues at
+// half rate on gfx950 (tools/valu_rates.hip: 4.1 cycles, AND+BCNT 6.25 cycles per
+// 64 x 32 sample-pairs = 330 bit-MACs per cycle and SIMD); v_mfma_i32_32x32x32_i8 does 1024 MACs per
+// cycle and SIMD with exact int32 accumulation.  Price: every bit becomes a byte.
+// That expansion (3 VALU per 4 samples) is done once per workgroup while the chunk
+// is staged to LDS, not per wave.
+//
+// Workgroup = 4 waves = 64 x 64 SNP pairs, wave (wy, wx) owns 32 x 32 of them:
+// 4 corner products x 2 groups = 8 accumulator tiles (128 registers).
+// LDS image per buffer: [class aa|bb][64 A rows + 64 B rows][128 sample bytes + 16 pad];
+// the 144-byte pitch keeps both the b128 fragment reads and the b128 expansion
+// stores conflict-free (MI355X LDS banking: 16-byte slot = (addr/16) mod 16 resp. mod 8).
+// Two buffers: chunk k+1 is expanded while chunk k's MFMAs run; chunk k+2's
+// global loads are in flight.  A and B fragments use the same lane -> sample map
+// (lane half h takes bytes 16h..16h+15 of a 32-sample step), which is all a dot
+// product needs.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int MT = 64;          // SNPs per workgroup tile side
+constexpr int MKC = 128;        // samples (= bytes per row) per chunk
+constexpr int MPITCH = MKC + 16;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 32 sample bits -> 32 bytes of 0/1 (two 16-byte stores)
+__device__ __forceinline__ void expand32(uint32_t w, uint8_t *dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            v[d] = __umul24(__builtin_amdgcn_ubfe(w, 16 * q + 4 * d, 4), 0x00204081u) & 0x01010101u;
+        *reinterpret_cast<u32x4 *>(dst + 16 * q) = v;
+    }
+}
+}  // namespace
+
+template <int I, int N, typename F>
+__device__ __forceinline__ bool static_for_while(F &&f) {
+    if constexpr (I < N) {
+        if (!f(std::integral_constant<int, I>{})) return false;
+        return static_for_while<I + 1, N>(f);
+    }
+    return true;
+}
+
+template <bool PRE>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
+    // two LDS images [class][row][byte], separate objects so that stores into one and fragment reads
+    // of the other can be interleaved
+    __shared__ __attribute__((aligned(16))) uint8_t sX0[2][2 * MT][MPITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sX1[2][2 * MT][MPITCH];
+
+    const uint32_t a0 = a.a_begin + blockIdx.y * MT, b0 = a.b_begin + blockIdx.x * MT;
+    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
+    if (a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;  // nothing above the diagonal in this tile
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t wy = wave >> 1, wx = wave & 1u;
+
+    // staging: thread t expands 64 samples (half hf of the chunk) of row t >> 1 (0..63 A, 64..127 B).
+    // The plane words of the next RING chunks wait in registers: the compacted table of a large
+    // job lives in the Infinity Cache, ~2 us away, an iteration is ~0.5 us.
+    constexpr int RING = 4;
+    const uint32_t srow = t >> 1, hf = t & 1u;
+    const uint32_t ssnp = srow < (uint32_t)MT ? min(a0 + srow, a_end - 1u) : min(b0 + (srow - MT), b_end - 1u);
+    const uint32_t *grow = a.cc + (uint64_t)ssnp * a.cc_stride_w + 2u * hf;
+    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;  // planes are whole chunks (x 32 words)
+    uint2 n0[RING], n1[RING];
+    auto fetch = [&](uint32_t c, uint2 &p0, uint2 &p1) {
+        const bool ctrl = c >= nchunk_c;
+        const uint32_t off = ctrl ? 2u * a.wc + (c - nchunk_c) * 4u : c * 4u;
+        const uint32_t wn = ctrl ? a.wt : a.wc;
+        p0 = *reinterpret_cast<const uint2 *>(grow + off);
+        p1 = *reinterpret_cast<const uint2 *>(grow + off + wn);
+    };
+    uint8_t *const st0 = &sX0[0][srow][64u * hf], *const st1 = &sX1[0][srow][64u * hf];
+    constexpr uint32_t CLS = 2u * MT * MPITCH;  // class stride inside an image
+    // quarter q of a chunk's expansion: class q & 1 (aa, bb) of word q >> 1
+    auto stash_quarter = [&](uint8_t *dst, const uint2 &p0, const uint2 &p1, int q) {
+        const uint32_t w0 = (q >> 1) ? p0.y : p0.x, w1 = (q >> 1) ? p1.y : p1.x;
+        expand32((q & 1) ? (w0 & w1) : (w0 & ~w1), dst + (q & 1) * CLS + 32 * (q >> 1));
+    };
+
+    i32x16 acc[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][c][r] = 0;
+
+    const uint32_t fr = lane & 31u, fh = lane >> 5;
+    const uint8_t *const fa0 = &sX0[0][wy * 32u + fr][16u * fh], *const fb0 = &sX0[0][MT + wx * 32u + fr][16u * fh];
+    const uint8_t *const fa1 = &sX1[0][wy * 32u + fr][16u * fh], *const fb1 = &sX1[0][MT + wx * 32u + fr][16u * fh];
+
+    // one chunk: 4 steps of 32 samples; after each step's MFMAs a quarter of the NEXT chunk is expanded
+    // into the other image (its stores cannot touch what this chunk still reads)
+    struct Frag { i32x4 xa, xb, ya, yb; };
+    auto load_frag = [&](const uint8_t *pa, const uint8_t *pb, int s) {
+        Frag f;
+        f.xa = *reinterpret_cast<const i32x4 *>(pa + 32 * s);
+        f.xb = *reinterpret_cast<const i32x4 *>(pa + CLS + 32 * s);
+        f.ya = *reinterpret_cast<const i32x4 *>(pb + 32 * s);
+        f.yb = *reinterpret_cast<const i32x4 *>(pb + CLS + 32 * s);
+        return f;
+    };
+    auto chunk = [&](const uint8_t *pa, const uint8_t *pb, i32x16 (&d)[4], uint8_t *dst, const uint2 &p0,
+                     const uint2 &p1, bool more) {
+        Frag cur = load_frag(pa, pb, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag nxt;
+            if (s < 3) nxt = load_frag(pa, pb, s + 1);
+            d[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xa, cur.ya, d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xa, cur.yb, d[1], 0, 0, 0);
+            d[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xb, cur.ya, d[2], 0, 0, 0);
+            d[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xb, cur.yb, d[3], 0, 0, 0);
+            if (more) stash_quarter(dst, p0, p1, s);
+            if (s < 3) cur = nxt;
+        }
+    };
+
+    // prologue: chunks 0 .. RING-1 in flight, chunk 0 expanded, its slot refilled with chunk RING
+    // (both groups' planes are whole multiples of 8 chunks, so every round below is complete)
+#pragma unroll
+    for (int k = 0; k < RING; ++k) fetch(k, n0[k], n1[k]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stash_quarter(st0, n0[0], n1[0], q);
+    fetch(RING, n0[0], n1[0]);
+    __syncthreads();
+
+    // a round = RING chunks; chunk c0 + k is read from image k & 1 while chunk c0 + k + 1 (register
+    // slot (k + 1) % RING) is expanded into the other one, and that slot is refilled RING chunks ahead
+    auto round = [&](uint32_t c0, i32x16 (&d)[4]) {
+        static_for<0, RING>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int nk = (k + 1) % RING;
+            const uint32_t c = c0 + k;
+            chunk(k & 1 ? fa1 : fa0, k & 1 ? fb1 : fb0, d, k & 1 ? st0 : st1, n0[nk], n1[nk], c + 1u < nchunk);
+            if (c + 1u + RING < nchunk) fetch(c + 1u + RING, n0[nk], n1[nk]);
+            __syncthreads();
+        });
+    };
+    for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0, acc[0]);
+    for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0, acc[1]);
+
+    // ---- per pair: corners -> tables -> bound / measure.  C layout of the 32x32 MFMA:
+    // column (B index) = lane & 31, row (A index) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * 32u + 4u * fh;
+    const bool j_ok = j < b_end;
+    const SnpMargin *pm2 = a.mar + (j_ok ? j : b_end - 1u);
+    uint32_t f2c[3], f2t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f2c[k] = pm2->cases[k]; f2t[k] = pm2->ctrls[k]; }
+    SnpMarginF mf2;
+    if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
+    const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
+
+    auto tables = [&](const uint32_t (&c4)[2][4], const uint32_t *f1c, const uint32_t *f1t, uint32_t (&ca)[9],
+                      uint32_t (&co)[9]) {
+        // table5.cpp:1088-1106 / 1125-1143: corners counted, the rest from the margins
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t *f1 = g == 0 ? f1c : f1t;
+            const uint32_t *f2 = g == 0 ? f2c : f2t;
+            uint32_t *o = g == 0 ? ca : co;
+            o[0] = c4[g][0]; o[2] = c4[g][1]; o[6] = c4[g][2]; o[8] = c4[g][3];
+            o[1] = f1[0] - o[0] - o[2];
+            o[7] = f1[2] - o[8] - o[6];
+            o[3] = f2[0] - o[0] - o[6];
+            o[5] = f2[2] - o[2] - o[8];
+            o[4] = f2[1] - o[1] - o[7];
+        }
+    };
+
+    uint32_t need = 0;  // bit r: pair of accumulator register r still wants its FP64 measure
+    unsigned long long n_eval = 0;
+    static_for<0, 16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+        if (i < a_end && j_ok && i < j) {
+            ++n_eval;
+            if (PRE) {
+                const SnpMargin *pm1 = a.mar + i;
+                uint32_t c4[2][4], ca[9], co[9];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r];
+                tables(c4, pm1->cases, pm1->ctrls, ca, co);
+                const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n);
+                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
+                else if (!(bound < a.bound_threshold)) need |= 1u << r;
+            } else {
+                need |= 1u << r;
+            }
+        }
+        asm volatile("" ::: "memory");  // one pair at a time: keeps 16 pairs' margin loads from being hoisted
+    });
+
+    double vmax = -1.0e300, vmin = 1.0e300;
+    while (need) {  // FP64 measure, one accumulator register at a time (per lane its own)
+        const int r = __ffs((int)need) - 1;
+        need &= need - 1u;
+        uint32_t c4[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v = r == q ? (uint32_t)acc[g][k][q] : v;
+                c4[g][k] = v;
+            }
+        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+        const SnpMargin m1 = a.mar[i], m2 = *pm2;
+        uint32_t ca[9], co[9];
+        tables(c4, m1.cases, m1.ctrls, ca, co);
+        const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+        if (!PRE) {
+            vmax = fmax(vmax, measure);
+            vmin = fmin(vmin, measure);
+        }
+        if (measure > a.threshold) {  // :482-484
+            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+            if (slot < a.max_hits) {
+                BoostHit h;
+                h.snp_a = i;
+                h.snp_b = j;
+                h.measure = measure;
+                a.hits[slot] = h;
+            }
+        }
+        if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_xor(n_eval, off, 64);
+        if (!PRE) {
+            vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+            vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
+        }
+    }
+    if (lane == 0 && n_eval) {
+        atomicAdd(&a.tally[1], n_eval);
+        if (!PRE) {
+            atomicMax(&a.tally[2], ordered(vmax));
+            atomicMin(&a.tally[3], ordered(vmin));
+        }
+    }
+}
+
 hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
                         const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
                         uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold) {
+                        float bound_threshold, bool matrix_cores) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -440,6 +709,12 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.n_individs = (int)n_individs; a.threshold = threshold;
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
     a.marf = d_marf; a.bound_threshold = bound_threshold;
+    if (matrix_cores && fast) {
+        const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
+        if (prefilter && d_marf) hipLaunchKernelGGL(k_boost_mfma<true>, mgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(k_boost_mfma<false>, mgrid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     const dim3 grid((n_b + TB - 1) / TB, (n_a + TA - 1) / TA);
     if (prefilter && d_marf) {
         if (fast) hipLaunchKernelGGL((k_boost<true, true>), grid, dim3(256), 0, stream, a);

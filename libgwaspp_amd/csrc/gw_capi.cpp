@@ -88,7 +88,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1;
 };
 
 namespace {
@@ -859,7 +859,8 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     if (e == hipSuccess)
         e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
                              (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
-                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr);
+                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr,
+                             t->opt_boost_mfma != 0);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -1004,6 +1005,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "complement must be 0 (never), 1 (auto) or 2 (whenever possible)");
         t->opt_complement = (int)v;
         return GW_OK;
+    case GW_OPT_BOOST_MATRIX_CORES:
+        t->opt_boost_mfma = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
         t->opt_prefilter = (int)v;
@@ -1025,6 +1029,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
+    case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma && t->selected_valid && !t->any_missing; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }
 }

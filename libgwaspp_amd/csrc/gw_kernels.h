@@ -117,6 +117,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         bool fast, hipStream_t stream,
                         // FP32 bound first (prefilter), the FP64 measure only where it cannot rule a pair out;
                         // no extremes in d_tally then; with d_dense the bound itself is written (diagnostic)
-                        const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f);
+                        const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f,
+                        // tables without a missing call: corners as int8 MFMA dot products (k_boost_mfma)
+                        bool matrix_cores = false);
 
 }  // namespace gw

@@ -19,12 +19,15 @@ ap.add_argument("--snps", type=int, default=100_000)
 ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--missing-q16", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--valu", action="store_true", help="AND + popcount kernel instead of the int8 MFMA one")
 args = ap.parse_args()
 
 m, n = args.snps, args.samples
 t = gw.GwTable(n, m)
 t.simulate(0x5EED, 0, args.missing_q16)
 t.simulate_phenotype(0x5EED)
+if args.valu:
+    t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, 0)
 t0 = time.perf_counter()
 t.boost_screen(0, min(m, 64), 0, min(m, 64))  # builds the compacted rows + margins
 prep = time.perf_counter() - t0
@@ -48,6 +51,7 @@ out = {"metric": "SNP pairs/s, BOOST KSA pre-screen", "value": n_pairs / best, "
        "same_hit_list": bool(same), "prep_seconds": prep,
        "hits_over_30": n_hits, "max_measure": vmax, "min_measure": vmin,
        "popcount_path": "4 corners + margins" if args.missing_q16 == 0 else "9 cells",
+       "matrix_cores": bool(t.get_option(gw.capi.OPT_BOOST_MATRIX_CORES)),
        "and_popc_per_s": n_pairs / best * (n / 32.0) * (4 if args.missing_q16 == 0 else 9)}
 print(json.dumps(out))
 t.close()
