@@ -257,6 +257,7 @@ struct BoostArgs {
     unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
     double *dense;              // n_a x n_b, or null
     const SnpMarginF *marf;     // PRE only
+    const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
     float bound_threshold;      // PRE: pairs whose FP32 bound is below this are not hits
 };
 
@@ -438,62 +439,99 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Block-tiled copy of the compacted rows for k_boost_mfma:
+//   unit (snp, chunk c, half h) = {plane0 words 4c+2h, 4c+2h+1, plane1 words 4c+2h, 4c+2h+1}
+//   at 16-byte index (((snp >> 6) * nchunk + c) * 64 + (snp & 63)) * 2 + h,
+// chunks of the case planes first, then the control planes.
+// ---------------------------------------------------------------------------
+__global__ void k_retile_cc(const uint32_t *cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
+                            u32x4 *cct) {
+    const uint32_t nchunk_c = wc / 4u, nchunk = nchunk_c + wt / 4u;
+    const uint64_t total = (uint64_t)n_snps * nchunk * 2u;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = (uint32_t)(idx & 1u);
+        const uint64_t rc = idx >> 1;
+        const uint32_t c = (uint32_t)(rc % nchunk), snp = (uint32_t)(rc / nchunk);
+        const bool ctrl = c >= nchunk_c;
+        const uint32_t off = (ctrl ? 2u * wc + (c - nchunk_c) * 4u : c * 4u) + 2u * h;
+        const uint32_t wn = ctrl ? wt : wc;
+        const uint32_t *src = cc + (uint64_t)snp * cc_stride_w + off;
+        u32x4 v;
+        v[0] = src[0]; v[1] = src[1]; v[2] = src[wn]; v[3] = src[wn + 1u];
+        cct[(((uint64_t)(snp >> 6) * nchunk + c) * 64u + (snp & 63u)) * 2u + h] = v;
+    }
+}
+
+hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
+                            u32x4 *d_cct, hipStream_t stream) {
+    if (n_snps == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_retile_cc, dim3(4096), dim3(256), 0, stream, d_cc, cc_stride_w, wc, wt, n_snps, d_cct);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Matrix-core form of the same tile (tables without a missing call).
 //
 // The four counted corners of a pair are dot products of 0/1 class vectors over
 // the samples of a group -- a binary GEMM, and unlike the per-SNP scan it re-uses
 // every row M times, so it is compute- not HBM-bound.  v_bcnt_u32_b32 issues at
-// half rate on gfx950 (tools/valu_rates.hip: 4.1 cycles, AND+BCNT 6.25 cycles per
-// 64 x 32 sample-pairs = 330 bit-MACs per cycle and SIMD); v_mfma_i32_32x32x32_i8 does 1024 MACs per
-// cycle and SIMD with exact int32 accumulation.  Price: every bit becomes a byte.
-// That expansion (3 VALU per 4 samples) is done once per workgroup while the chunk
-// is staged to LDS, not per wave.
+// half rate on gfx950 (tools/valu_rates.hip: 4.1 cycles; AND+BCNT 6.25 cycles per
+// 64 x 32 sample pairs = 330 bit-MACs per cycle and SIMD); v_mfma_i32_32x32x32_i8
+// does 1024 MACs per cycle and SIMD with exact int32 accumulation.  Price: every
+// bit must become a byte.
 //
-// Workgroup = 4 waves = 64 x 64 SNP pairs, wave (wy, wx) owns 32 x 32 of them:
-// 4 corner products x 2 groups = 8 accumulator tiles (128 registers).
-// LDS image per buffer: [class aa|bb][64 A rows + 64 B rows][128 sample bytes + 16 pad];
-// the 144-byte pitch keeps both the b128 fragment reads and the b128 expansion
-// stores conflict-free (MI355X LDS banking: 16-byte slot = (addr/16) mod 16 resp. mod 8).
-// Two buffers: chunk k+1 is expanded while chunk k's MFMAs run; chunk k+2's
-// global loads are in flight.  A and B fragments use the same lane -> sample map
-// (lane half h takes bytes 16h..16h+15 of a 32-sample step), which is all a dot
-// product needs.
+// Wave = 32 x 32 SNP pairs: 4 corner products x 2 groups = 8 accumulator tiles
+// (128 registers); workgroup = 2 x 2 waves that share nothing but the epilogue's
+// margins.  No LDS and no barrier in the main loop: a first version that expanded
+// each chunk once per workgroup into LDS was bound by LDS *stores* (ds_write_b128
+// moves 79 B/clk/CU, the expanded operands of a 64 x 64 tile need 64 B/clk at the
+// MFMA rate) and reached 48 % of the matrix peak.  Here every lane loads the 64
+// sample bits it needs straight from the block-tiled table (k_retile_cc: lane
+// (r, h) = row r, half h of the chunk, one 16-byte load, 1 KiB contiguous per wave)
+// and expands them in registers.  The K order inside a chunk is ours to choose as
+// long as A and B agree: lane half h owns samples 64h .. 64h+63, step s takes
+// 16s .. 16s+15 of them.
+//
+// Expansion in 2 VALU per 4 samples instead of 3: v_perm_b32 replicates the byte
+// holding the nibble, v_and_b32 isolates bit m in byte m -- so A's byte m carries
+// weight 2^m; B is taken from the bit-reversed word so that its byte m carries
+// 2^(3-m): every product is 8 and the accumulators hold 8 x count (exact; >> 3).
 // ---------------------------------------------------------------------------
 namespace {
-constexpr int MT = 64;          // SNPs per workgroup tile side
-constexpr int MKC = 128;        // samples (= bytes per row) per chunk
-constexpr int MPITCH = MKC + 16;
+constexpr int MT = 64;  // SNPs per workgroup tile side
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// 32 sample bits -> 32 bytes of 0/1 (two 16-byte stores)
-__device__ __forceinline__ void expand32(uint32_t w, uint8_t *dst) {
+// samples 16 hw .. 16 hw + 15 of word w (hw = 0, 1) as 16 bytes, byte m of each dword weighted 2^m
+__device__ __forceinline__ i32x4 expand_a(uint32_t w, uint32_t w_shr4, int hw) {
+    i32x4 v;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        u32x4 v;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-            v[d] = __umul24(__builtin_amdgcn_ubfe(w, 16 * q + 4 * d, 4), 0x00204081u) & 0x01010101u;
-        *reinterpret_cast<u32x4 *>(dst + 16 * q) = v;
+    for (int e = 0; e < 4; ++e) {
+        const int d = 4 * hw + e;                       // nibble of the word
+        const uint32_t src = (d & 1) ? w_shr4 : w;      // nibble d in the low half of byte d >> 1
+        const uint32_t sel = 0x01010101u * (uint32_t)(d >> 1);
+        v[e] = (int)(__builtin_amdgcn_perm(src, src, sel) & 0x08040201u);
     }
+    return v;
+}
+// the same samples from the bit-reversed word, byte m weighted 2^(3-m)
+__device__ __forceinline__ i32x4 expand_b(uint32_t rw, uint32_t rw_shr4, int hw) {
+    i32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int d = 4 * hw + e;
+        const uint32_t src = (d & 1) ? rw : rw_shr4;    // sample 4d+m sits at bit 3-m of byte 3 - (d >> 1)
+        const uint32_t sel = 0x01010101u * (uint32_t)(3 - (d >> 1));
+        v[e] = (int)(__builtin_amdgcn_perm(src, src, sel) & 0x01020408u);
+    }
+    return v;
 }
 }  // namespace
 
-template <int I, int N, typename F>
-__device__ __forceinline__ bool static_for_while(F &&f) {
-    if constexpr (I < N) {
-        if (!f(std::integral_constant<int, I>{})) return false;
-        return static_for_while<I + 1, N>(f);
-    }
-    return true;
-}
-
 template <bool PRE>
 __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
-    // two LDS images [class][row][byte], separate objects so that stores into one and fragment reads
-    // of the other can be interleaved
-    __shared__ __attribute__((aligned(16))) uint8_t sX0[2][2 * MT][MPITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t sX1[2][2 * MT][MPITCH];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mar[MT * 32];  // the A rows' margins (epilogue)
 
     const uint32_t a0 = a.a_begin + blockIdx.y * MT, b0 = a.b_begin + blockIdx.x * MT;
     const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
@@ -501,30 +539,14 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t wy = wave >> 1, wx = wave & 1u;
+    const uint32_t fr = lane & 31u, fh = lane >> 5;
 
-    // staging: thread t expands 64 samples (half hf of the chunk) of row t >> 1 (0..63 A, 64..127 B).
-    // The plane words of the next RING chunks wait in registers: the compacted table of a large
-    // job lives in the Infinity Cache, ~2 us away, an iteration is ~0.5 us.
-    constexpr int RING = 4;
-    const uint32_t srow = t >> 1, hf = t & 1u;
-    const uint32_t ssnp = srow < (uint32_t)MT ? min(a0 + srow, a_end - 1u) : min(b0 + (srow - MT), b_end - 1u);
-    const uint32_t *grow = a.cc + (uint64_t)ssnp * a.cc_stride_w + 2u * hf;
-    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;  // planes are whole chunks (x 32 words)
-    uint2 n0[RING], n1[RING];
-    auto fetch = [&](uint32_t c, uint2 &p0, uint2 &p1) {
-        const bool ctrl = c >= nchunk_c;
-        const uint32_t off = ctrl ? 2u * a.wc + (c - nchunk_c) * 4u : c * 4u;
-        const uint32_t wn = ctrl ? a.wt : a.wc;
-        p0 = *reinterpret_cast<const uint2 *>(grow + off);
-        p1 = *reinterpret_cast<const uint2 *>(grow + off + wn);
-    };
-    uint8_t *const st0 = &sX0[0][srow][64u * hf], *const st1 = &sX1[0][srow][64u * hf];
-    constexpr uint32_t CLS = 2u * MT * MPITCH;  // class stride inside an image
-    // quarter q of a chunk's expansion: class q & 1 (aa, bb) of word q >> 1
-    auto stash_quarter = [&](uint8_t *dst, const uint2 &p0, const uint2 &p1, int q) {
-        const uint32_t w0 = (q >> 1) ? p0.y : p0.x, w1 = (q >> 1) ? p1.y : p1.x;
-        expand32((q & 1) ? (w0 & w1) : (w0 & ~w1), dst + (q & 1) * CLS + 32 * (q >> 1));
-    };
+    // this lane's A row and B row in the block-tiled table (rows past the block end repeat its last
+    // row; their pairs are never reported)
+    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;  // planes are whole multiples of 8 chunks
+    const uint32_t snp_a = min(a0 + wy * 32u + fr, a_end - 1u), snp_b = min(b0 + wx * 32u + fr, b_end - 1u);
+    const u32x4 *ga = a.cct + ((uint64_t)(snp_a >> 6) * nchunk * 64u + (snp_a & 63u)) * 2u + fh;
+    const u32x4 *gb = a.cct + ((uint64_t)(snp_b >> 6) * nchunk * 64u + (snp_b & 63u)) * 2u + fh;
 
     i32x16 acc[2][4];
 #pragma unroll
@@ -534,56 +556,56 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][c][r] = 0;
 
-    const uint32_t fr = lane & 31u, fh = lane >> 5;
-    const uint8_t *const fa0 = &sX0[0][wy * 32u + fr][16u * fh], *const fb0 = &sX0[0][MT + wx * 32u + fr][16u * fh];
-    const uint8_t *const fa1 = &sX1[0][wy * 32u + fr][16u * fh], *const fb1 = &sX1[0][MT + wx * 32u + fr][16u * fh];
+    // the next RING chunks' bits wait in registers (the table of a large job sits in L2 / Infinity
+    // Cache, 1-2 us away; a chunk takes ~0.25 us)
+    constexpr int RING = 4;
+    u32x4 ua[RING], ub[RING];  // {plane0 w0, plane0 w1, plane1 w0, plane1 w1} of the lane's 64 samples
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+        ua[k] = ga[(uint64_t)k * 128u];
+        ub[k] = gb[(uint64_t)k * 128u];
+    }
+    const uint32_t last_chunk = nchunk - 1u;
 
-    // one chunk: 4 steps of 32 samples; after each step's MFMAs a quarter of the NEXT chunk is expanded
-    // into the other image (its stores cannot touch what this chunk still reads)
     struct Frag { i32x4 xa, xb, ya, yb; };
-    auto load_frag = [&](const uint8_t *pa, const uint8_t *pb, int s) {
-        Frag f;
-        f.xa = *reinterpret_cast<const i32x4 *>(pa + 32 * s);
-        f.xb = *reinterpret_cast<const i32x4 *>(pa + CLS + 32 * s);
-        f.ya = *reinterpret_cast<const i32x4 *>(pb + 32 * s);
-        f.yb = *reinterpret_cast<const i32x4 *>(pb + CLS + 32 * s);
-        return f;
-    };
-    auto chunk = [&](const uint8_t *pa, const uint8_t *pb, i32x16 (&d)[4], uint8_t *dst, const uint2 &p0,
-                     const uint2 &p1, bool more) {
-        Frag cur = load_frag(pa, pb, 0);
+    // one chunk = 4 steps of 16 samples per lane half: step s = half (s & 1) of word (s >> 1)
+    auto chunk = [&](const u32x4 &va, const u32x4 &vb, i32x16 (&d)[4]) {
+        uint32_t caa[2], cbb[2], raa[2], rbb[2], caa4[2], cbb4[2], raa4[2], rbb4[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            caa[w] = va[w] & ~va[2 + w];                                      // A row: aa, bb
+            cbb[w] = va[w] & va[2 + w];
+            raa[w] = __builtin_bitreverse32(vb[w] & ~vb[2 + w]);              // B row, bit-reversed
+            rbb[w] = __builtin_bitreverse32(vb[w] & vb[2 + w]);
+            caa4[w] = caa[w] >> 4; cbb4[w] = cbb[w] >> 4; raa4[w] = raa[w] >> 4; rbb4[w] = rbb[w] >> 4;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            Frag nxt;
-            if (s < 3) nxt = load_frag(pa, pb, s + 1);
-            d[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xa, cur.ya, d[0], 0, 0, 0);
-            d[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xa, cur.yb, d[1], 0, 0, 0);
-            d[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xb, cur.ya, d[2], 0, 0, 0);
-            d[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.xb, cur.yb, d[3], 0, 0, 0);
-            if (more) stash_quarter(dst, p0, p1, s);
-            if (s < 3) cur = nxt;
+            Frag f;
+            f.xa = expand_a(caa[s >> 1], caa4[s >> 1], s & 1);
+            f.xb = expand_a(cbb[s >> 1], cbb4[s >> 1], s & 1);
+            f.ya = expand_b(raa[s >> 1], raa4[s >> 1], s & 1);
+            f.yb = expand_b(rbb[s >> 1], rbb4[s >> 1], s & 1);
+            d[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xa, f.ya, d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xa, f.yb, d[1], 0, 0, 0);
+            d[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xb, f.ya, d[2], 0, 0, 0);
+            d[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xb, f.yb, d[3], 0, 0, 0);
+            // issue order: an MFMA holds the matrix pipe for 32 cycles but the issue port for 8; the
+            // ~10 VALU of expansion per MFMA go between them (2.2 cycles each), not in front
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // 10 VALU
+            }
         }
     };
-
-    // prologue: chunks 0 .. RING-1 in flight, chunk 0 expanded, its slot refilled with chunk RING
-    // (both groups' planes are whole multiples of 8 chunks, so every round below is complete)
-#pragma unroll
-    for (int k = 0; k < RING; ++k) fetch(k, n0[k], n1[k]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) stash_quarter(st0, n0[0], n1[0], q);
-    fetch(RING, n0[0], n1[0]);
-    __syncthreads();
-
-    // a round = RING chunks; chunk c0 + k is read from image k & 1 while chunk c0 + k + 1 (register
-    // slot (k + 1) % RING) is expanded into the other one, and that slot is refilled RING chunks ahead
     auto round = [&](uint32_t c0, i32x16 (&d)[4]) {
         static_for<0, RING>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            constexpr int nk = (k + 1) % RING;
-            const uint32_t c = c0 + k;
-            chunk(k & 1 ? fa1 : fa0, k & 1 ? fb1 : fb0, d, k & 1 ? st0 : st1, n0[nk], n1[nk], c + 1u < nchunk);
-            if (c + 1u + RING < nchunk) fetch(c + 1u + RING, n0[nk], n1[nk]);
-            __syncthreads();
+            chunk(ua[k], ub[k], d);
+            const uint64_t nxt = (uint64_t)min(c0 + k + RING, last_chunk) * 128u;  // past the end: re-read, unused
+            ua[k] = ga[nxt];
+            ub[k] = gb[nxt];
         });
     };
     for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0, acc[0]);
@@ -600,6 +622,19 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
     SnpMarginF mf2;
     if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
     const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
+
+    // The 64 A rows' margins go through LDS: every lane needs 16 of them.
+    // Per row 32 dwords: cases[3], ctrls[3], pad[2], then the 24 floats of SnpMarginF.
+    for (uint32_t idx = t; idx < (uint32_t)MT * 32u; idx += 256u) {
+        const uint32_t row = idx >> 5, k = idx & 31u;
+        const uint32_t snp = min(a0 + row, a_end - 1u);
+        uint32_t v = 0;
+        if (k < 3u) v = a.mar[snp].cases[k];
+        else if (k < 6u) v = a.mar[snp].ctrls[k - 3u];
+        else if (k >= 8u && PRE) v = reinterpret_cast<const uint32_t *>(a.marf + snp)[k - 8u];
+        s_mar[idx] = v;
+    }
+    __syncthreads();
 
     auto tables = [&](const uint32_t (&c4)[2][4], const uint32_t *f1c, const uint32_t *f1t, uint32_t (&ca)[9],
                       uint32_t (&co)[9]) {
@@ -626,21 +661,28 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
         if (i < a_end && j_ok && i < j) {
             ++n_eval;
             if (PRE) {
-                const SnpMargin *pm1 = a.mar + i;
+                const uint32_t *row = s_mar + (i - a0) * 32u;
+                uint32_t f1[8];
+                *reinterpret_cast<u32x4 *>(f1) = *reinterpret_cast<const u32x4 *>(row);
+                *reinterpret_cast<u32x4 *>(f1 + 4) = *reinterpret_cast<const u32x4 *>(row + 4);
+                SnpMarginF mf1;
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    *reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(&mf1) + 4 * q) =
+                        *reinterpret_cast<const u32x4 *>(row + 8 + 4 * q);
                 uint32_t c4[2][4], ca[9], co[9];
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r];
-                tables(c4, pm1->cases, pm1->ctrls, ca, co);
-                const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n);
+                    for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r] >> 3;  // every product was 8
+                tables(c4, f1, f1 + 3, ca, co);
+                const float bound = boost_bound(ca, co, mf1, mf2, nf, inv_n);
                 if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
                 else if (!(bound < a.bound_threshold)) need |= 1u << r;
             } else {
                 need |= 1u << r;
             }
         }
-        asm volatile("" ::: "memory");  // one pair at a time: keeps 16 pairs' margin loads from being hoisted
     });
 
     double vmax = -1.0e300, vmin = 1.0e300;
@@ -655,7 +697,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
                 uint32_t v = 0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v = r == q ? (uint32_t)acc[g][k][q] : v;
-                c4[g][k] = v;
+                c4[g][k] = v >> 3;
             }
         const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
         const SnpMargin m1 = a.mar[i], m2 = *pm2;
@@ -701,7 +743,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, bool matrix_cores) {
+                        float bound_threshold, const u32x4 *d_cct) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -709,7 +751,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.n_individs = (int)n_individs; a.threshold = threshold;
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
     a.marf = d_marf; a.bound_threshold = bound_threshold;
-    if (matrix_cores && fast) {
+    a.cct = d_cct;
+    if (d_cct && fast) {
         const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
         if (prefilter && d_marf) hipLaunchKernelGGL(k_boost_mfma<true>, mgrid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(k_boost_mfma<false>, mgrid, dim3(256), 0, stream, a);

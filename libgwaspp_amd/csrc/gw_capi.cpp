@@ -77,6 +77,7 @@ struct gw_table {
     uint32_t wc = 0, wt = 0;
     gw::SnpMargin *d_mar = nullptr;
     gw::SnpMarginF *d_marf = nullptr;
+    gw::u32x4 *d_cct = nullptr;  // block-tiled copy of d_cc for the MFMA pair kernel (tables without missing calls)
     double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
@@ -335,6 +336,7 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_cc) (void)hipFree(t->d_cc);
     if (t->d_mar) (void)hipFree(t->d_mar);
     if (t->d_marf) (void)hipFree(t->d_marf);
+    if (t->d_cct) (void)hipFree(t->d_cct);
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
     if (t->d_tally) (void)hipFree(t->d_tally);
@@ -757,6 +759,7 @@ int ensure_selected(gw_table *t) {
     if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
     if (t->d_mar) { GW_HIP(hipFree(t->d_mar)); t->d_mar = nullptr; }
     if (t->d_marf) { GW_HIP(hipFree(t->d_marf)); t->d_marf = nullptr; }
+    if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
     if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long)));
     if (m) {
         GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
@@ -813,6 +816,13 @@ int ensure_selected(gw_table *t) {
     t->any_missing = false;
     for (uint64_t r = 0; r < m && !t->any_missing; ++r)
         t->any_missing = counts[r * 8 + 3] != 0 || counts[r * 8 + 7] != 0;
+    if (m && !t->any_missing) {  // the MFMA pair kernel reads a block-tiled copy
+        const size_t bytes = ((m + 63u) / 64u) * 64u * (size_t)((wc + wt) / 4u) * 32u;
+        GW_HIP(hipMalloc((void **)&t->d_cct, bytes));
+        GW_HIP(hipMemsetAsync(t->d_cct, 0, bytes, t->stream));
+        GW_HIP(gw::launch_retile_cc(t->d_cc, t->cc_stride_w, wc, wt, (uint32_t)m, t->d_cct, t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));
+    }
     t->selected_valid = true;
     return GW_OK;
 }
@@ -860,7 +870,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
                              (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
                              max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr,
-                             t->opt_boost_mfma != 0);
+                             t->opt_boost_mfma ? t->d_cct : nullptr);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);

@@ -119,6 +119,10 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         // no extremes in d_tally then; with d_dense the bound itself is written (diagnostic)
                         const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f,
                         // tables without a missing call: corners as int8 MFMA dot products (k_boost_mfma)
-                        bool matrix_cores = false);
+                        // over the block-tiled copy of the compacted rows (launch_retile_cc), or null
+                        const u32x4 *d_cct = nullptr);
+// bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
+hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
+                            u32x4 *d_cct, hipStream_t stream);
 
 }  // namespace gw
