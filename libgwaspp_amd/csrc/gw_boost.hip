@@ -493,37 +493,37 @@ hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t
 // long as A and B agree: lane half h owns samples 64h .. 64h+63, step s takes
 // 16s .. 16s+15 of them.
 //
-// Expansion in 2 VALU per 4 samples instead of 3: v_perm_b32 replicates the byte
-// holding the nibble, v_and_b32 isolates bit m in byte m -- so A's byte m carries
-// weight 2^m; B is taken from the bit-reversed word so that its byte m carries
-// 2^(3-m): every product is 8 and the accumulators hold 8 x count (exact; >> 3).
+// Expansion in ~1.3 VALU per 4 samples: the K order is free, so an operand dword
+// takes one sample from each byte of the word -- a single v_and_b32 -- and carries
+// a power-of-two weight that its partner compensates (expand_a / expand_b): every
+// product is 64 and the accumulators hold 64 x count (exact; >> 6).
 // ---------------------------------------------------------------------------
 namespace {
 constexpr int MT = 64;  // SNPs per workgroup tile side
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// samples 16 hw .. 16 hw + 15 of word w (hw = 0, 1) as 16 bytes, byte m of each dword weighted 2^m
-__device__ __forceinline__ i32x4 expand_a(uint32_t w, uint32_t w_shr4, int hw) {
+// Operand dword k (k = 0..7) of a 32-sample word = samples {k, 8+k, 16+k, 24+k}, one per byte: a single
+// v_and_b32 with 0x01010101 << k isolates them, leaving weight 2^k in every byte.  B takes the same
+// samples from the word with the bits of each byte reversed and shifted down by one, weight 2^(6-k):
+// every product is 64.  Bit 7 of a byte would be the int8 sign, so k = 7 is done with a shift
+// (A weight 1, B weight 64).  One fragment (step) = dwords 4hk .. 4hk+3 of one word.
+__device__ __forceinline__ i32x4 expand_a(uint32_t w, int hk) {
     i32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int d = 4 * hw + e;                       // nibble of the word
-        const uint32_t src = (d & 1) ? w_shr4 : w;      // nibble d in the low half of byte d >> 1
-        const uint32_t sel = 0x01010101u * (uint32_t)(d >> 1);
-        v[e] = (int)(__builtin_amdgcn_perm(src, src, sel) & 0x08040201u);
+        const int k = 4 * hk + e;
+        v[e] = k < 7 ? (int)(w & (0x01010101u << k)) : (int)((w >> 7) & 0x01010101u);
     }
     return v;
 }
-// the same samples from the bit-reversed word, byte m weighted 2^(3-m)
-__device__ __forceinline__ i32x4 expand_b(uint32_t rw, uint32_t rw_shr4, int hw) {
+// rb = the B word with the bits of each byte reversed, >> 1 (bit 6-k of byte m = sample 8m+k, k <= 6)
+__device__ __forceinline__ i32x4 expand_b(uint32_t w, uint32_t rb, int hk) {
     i32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int d = 4 * hw + e;
-        const uint32_t src = (d & 1) ? rw : rw_shr4;    // sample 4d+m sits at bit 3-m of byte 3 - (d >> 1)
-        const uint32_t sel = 0x01010101u * (uint32_t)(3 - (d >> 1));
-        v[e] = (int)(__builtin_amdgcn_perm(src, src, sel) & 0x01020408u);
+        const int k = 4 * hk + e;
+        v[e] = k < 7 ? (int)(rb & (0x01010101u << (6 - k))) : (int)((w >> 1) & 0x40404040u);
     }
     return v;
 }
@@ -570,32 +570,33 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
     struct Frag { i32x4 xa, xb, ya, yb; };
     // one chunk = 4 steps of 16 samples per lane half: step s = half (s & 1) of word (s >> 1)
     auto chunk = [&](const u32x4 &va, const u32x4 &vb, i32x16 (&d)[4]) {
-        uint32_t caa[2], cbb[2], raa[2], rbb[2], caa4[2], cbb4[2], raa4[2], rbb4[2];
+        uint32_t caa[2], cbb[2], baa[2], bbb[2], raa[2], rbb[2];
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-            caa[w] = va[w] & ~va[2 + w];                                      // A row: aa, bb
+            caa[w] = va[w] & ~va[2 + w];  // A row: aa, bb
             cbb[w] = va[w] & va[2 + w];
-            raa[w] = __builtin_bitreverse32(vb[w] & ~vb[2 + w]);              // B row, bit-reversed
-            rbb[w] = __builtin_bitreverse32(vb[w] & vb[2 + w]);
-            caa4[w] = caa[w] >> 4; cbb4[w] = cbb[w] >> 4; raa4[w] = raa[w] >> 4; rbb4[w] = rbb[w] >> 4;
+            baa[w] = vb[w] & ~vb[2 + w];  // B row
+            bbb[w] = vb[w] & vb[2 + w];
+            raa[w] = __builtin_bswap32(__builtin_bitreverse32(baa[w])) >> 1;
+            rbb[w] = __builtin_bswap32(__builtin_bitreverse32(bbb[w])) >> 1;
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             Frag f;
-            f.xa = expand_a(caa[s >> 1], caa4[s >> 1], s & 1);
-            f.xb = expand_a(cbb[s >> 1], cbb4[s >> 1], s & 1);
-            f.ya = expand_b(raa[s >> 1], raa4[s >> 1], s & 1);
-            f.yb = expand_b(rbb[s >> 1], rbb4[s >> 1], s & 1);
+            f.xa = expand_a(caa[s >> 1], s & 1);
+            f.xb = expand_a(cbb[s >> 1], s & 1);
+            f.ya = expand_b(baa[s >> 1], raa[s >> 1], s & 1);
+            f.yb = expand_b(bbb[s >> 1], rbb[s >> 1], s & 1);
             d[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xa, f.ya, d[0], 0, 0, 0);
             d[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xa, f.yb, d[1], 0, 0, 0);
             d[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xb, f.ya, d[2], 0, 0, 0);
             d[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.xb, f.yb, d[3], 0, 0, 0);
             // issue order: an MFMA holds the matrix pipe for 32 cycles but the issue port for 8; the
-            // ~10 VALU of expansion per MFMA go between them (2.2 cycles each), not in front
+            // ~6 VALU of expansion per MFMA go between them, not in front
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // 10 VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // 6 VALU
             }
         }
     };
@@ -674,7 +675,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r] >> 3;  // every product was 8
+                    for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r] >> 6;  // every product was 64
                 tables(c4, f1, f1 + 3, ca, co);
                 const float bound = boost_bound(ca, co, mf1, mf2, nf, inv_n);
                 if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
@@ -697,7 +698,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
                 uint32_t v = 0;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v = r == q ? (uint32_t)acc[g][k][q] : v;
-                c4[g][k] = v >> 3;
+                c4[g][k] = v >> 6;
             }
         const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
         const SnpMargin m1 = a.mar[i], m2 = *pm2;
