@@ -261,9 +261,10 @@ typedef enum gw_option {
                                 measure only where bound >= threshold - slack (slack = 2n * 1e-4 + 0.05;
                                 the hit list is the same, listed measures are the FP64 ones); 0 never;
                                 2 diagnostic: gw_boost_measures returns the bound instead of the measure */
-    GW_OPT_BOOST_MATRIX_CORES = 9, /* pair tables of a table without missing calls as int8 MFMA dot products
-                                (1, default) or AND + popcount on the vector ALU (0; always used when a
-                                call is missing); get returns whether the current table takes the MFMA path */
+    GW_OPT_BOOST_MATRIX_CORES = 9, /* pair tables as int8 MFMA dot products of class vectors (1, default: four
+                                products per pair when no call of the table is missing, nine otherwise)
+                                or AND + popcount on the vector ALU (0); 2 = as 1 but the nine-cell form
+                                always on 16x16 tiles (its fallback for case groups >= 65 536 members) */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

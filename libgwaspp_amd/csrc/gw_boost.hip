@@ -738,13 +738,385 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same on tables WITH missing calls: all nine cells of both 3 x 3 tables are
+// counted (table5.cpp:989-1064), nine products per pair and group.  Nine 32 x 32
+// accumulator tiles per group would be 288 registers, so this form uses
+// v_mfma_i32_16x16x64_i8 (4 registers per product): one wave = 16 A rows x 32 B
+// rows (two 16-row B tiles) = 2 x 9 x 2 x 4 = 144 accumulators; workgroup =
+// 2 x 2 waves = 32 x 64 pairs.  Lane (r, q) = row r of the tile, k-group q: it
+// owns samples 32q .. 32q+31 of the chunk (one word per plane), two steps of 16.
+// Operand expansion as in k_boost_mfma (expand_a / expand_b, products of 64).
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int M9A = 32, M9B = 64;  // workgroup tile: A rows x B rows
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+}  // namespace
+
+template <bool PRE>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma9(BoostArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_marf[(M9A + M9B) * 24];  // SnpMarginF of the tile's rows
+
+    const uint32_t a0 = a.a_begin + blockIdx.y * M9A, b0 = a.b_begin + blockIdx.x * M9B;
+    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
+    if (a0 + 1u >= min(b0 + (uint32_t)M9B, b_end)) return;  // nothing above the diagonal in this tile
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t wy = wave >> 1, wx = wave & 1u;
+    const uint32_t fr = lane & 15u, fq = lane >> 4;
+
+    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;
+    auto unit = [&](uint32_t snp) {  // this lane's 16-byte unit of chunk 0: half fq >> 1 of the row
+        return a.cct + ((uint64_t)(snp >> 6) * nchunk * 64u + (snp & 63u)) * 2u + (fq >> 1);
+    };
+    const u32x4 *ga = unit(min(a0 + wy * 16u + fr, a_end - 1u));
+    const u32x4 *gb0 = unit(min(b0 + wx * 32u + fr, b_end - 1u));
+    const u32x4 *gb1 = unit(min(b0 + wx * 32u + 16u + fr, b_end - 1u));
+    const uint32_t ws = fq & 1u;  // which word of the half
+
+    i32x4v acc[2][2][9];  // [group][B tile][3 * class of A + class of B]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc[g][tb][c] = i32x4v{0, 0, 0, 0};
+
+    constexpr int RING = 4;
+    uint2 ua[RING], ub0[RING], ub1[RING];  // {plane 0 word, plane 1 word} of the lane's 32 samples
+    auto fetch = [&](uint32_t c, uint2 &xa, uint2 &xb0, uint2 &xb1) {
+        const u32x4 va = ga[(uint64_t)c * 128u], vb0 = gb0[(uint64_t)c * 128u], vb1 = gb1[(uint64_t)c * 128u];
+        xa = ws ? make_uint2(va[1], va[3]) : make_uint2(va[0], va[2]);
+        xb0 = ws ? make_uint2(vb0[1], vb0[3]) : make_uint2(vb0[0], vb0[2]);
+        xb1 = ws ? make_uint2(vb1[1], vb1[3]) : make_uint2(vb1[0], vb1[2]);
+    };
+#pragma unroll
+    for (int k = 0; k < RING; ++k) fetch(k, ua[k], ub0[k], ub1[k]);
+    const uint32_t last_chunk = nchunk - 1u;
+
+    auto chunk = [&](const uint2 &pa, const uint2 &pb0, const uint2 &pb1, i32x4v (&d)[2][9]) {
+        // class words: aa = code 1, ab = code 2, bb = code 3 (plane0 = codes 1,3; plane1 = codes 2,3)
+        const uint32_t ca3[3] = {pa.x & ~pa.y, pa.y & ~pa.x, pa.x & pa.y};
+        uint32_t cb3[2][3], rb3[2][3];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const uint2 &pb = tb ? pb1 : pb0;
+            cb3[tb][0] = pb.x & ~pb.y; cb3[tb][1] = pb.y & ~pb.x; cb3[tb][2] = pb.x & pb.y;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rb3[tb][c] = __builtin_bswap32(__builtin_bitreverse32(cb3[tb][c])) >> 1;
+        }
+#pragma unroll
+        for (int hk = 0; hk < 2; ++hk) {
+            i32x4 xa[3], yb[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xa[c] = expand_a(ca3[c], hk);
+                yb[0][c] = expand_b(cb3[0][c], rb3[0][c], hk);
+                yb[1][c] = expand_b(cb3[1][c], rb3[1][c], hk);
+            }
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y)
+                        d[tb][3 * x + y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[x], yb[tb][y], d[tb][3 * x + y], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 18; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (16 cycles)
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // 3 VALU
+            }
+        }
+    };
+    auto round = [&](uint32_t c0, i32x4v (&d)[2][9]) {
+        static_for<0, RING>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            chunk(ua[k], ub0[k], ub1[k], d);
+            fetch(min(c0 + k + RING, last_chunk), ua[k], ub0[k], ub1[k]);  // past the end: re-read, unused
+        });
+    };
+    for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0, acc[0]);
+    for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0, acc[1]);
+
+    // ---- per pair.  C layout of the 16x16 MFMA: column (B index) = lane & 15, row (A index) = 4 (lane >> 4) + reg
+    if (PRE) {
+        for (uint32_t idx = t; idx < (uint32_t)(M9A + M9B) * 24u; idx += 256u) {
+            const uint32_t row = idx / 24u, k = idx % 24u;
+            const uint32_t snp = row < (uint32_t)M9A ? min(a0 + row, a_end - 1u) : min(b0 + (row - M9A), b_end - 1u);
+            s_marf[idx] = reinterpret_cast<const uint32_t *>(a.marf + snp)[k];
+        }
+        __syncthreads();
+    }
+    const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
+    const uint32_t i_base = a0 + wy * 16u + 4u * fq;
+    auto load_marf = [&](uint32_t row) {
+        SnpMarginF m;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            *reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(&m) + 4 * q) =
+                *reinterpret_cast<const u32x4 *>(s_marf + row * 24u + 4 * q);
+        return m;
+    };
+
+    uint32_t need = 0;  // bit 4 tb + reg: that pair still wants its FP64 measure
+    unsigned long long n_eval = 0;
+    static_for<0, 8>([&](auto pc) {
+        constexpr int tb = decltype(pc)::value >> 2, r = decltype(pc)::value & 3;
+        const uint32_t i = i_base + r, j = b0 + wx * 32u + tb * 16u + fr;
+        if (i < a_end && j < b_end && i < j) {
+            ++n_eval;
+            if (PRE) {
+                uint32_t ca[9], co[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    ca[c] = (uint32_t)acc[0][tb][c][r] >> 6;  // every product was 64
+                    co[c] = (uint32_t)acc[1][tb][c][r] >> 6;
+                }
+                const float bound = boost_bound(ca, co, load_marf(i - a0), load_marf(M9A + (j - b0)), nf, inv_n);
+                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
+                else if (!(bound < a.bound_threshold)) need |= 1u << (4 * tb + r);
+            } else {
+                need |= 1u << (4 * tb + r);
+            }
+        }
+    });
+
+    double vmax = -1.0e300, vmin = 1.0e300;
+    while (need) {
+        const int p = __ffs((int)need) - 1;
+        need &= need - 1u;
+        uint32_t ca[9], co[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            uint32_t x = 0, y = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                x = p == q ? (uint32_t)acc[0][q >> 2][c][q & 3] : x;
+                y = p == q ? (uint32_t)acc[1][q >> 2][c][q & 3] : y;
+            }
+            ca[c] = x >> 6;
+            co[c] = y >> 6;
+        }
+        const uint32_t i = i_base + (p & 3), j = b0 + wx * 32u + (p >> 2) * 16u + fr;
+        const SnpMargin m1 = a.mar[i], m2 = a.mar[j];
+        const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+        if (!PRE) {
+            vmax = fmax(vmax, measure);
+            vmin = fmin(vmin, measure);
+        }
+        if (measure > a.threshold) {  // :482-484
+            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+            if (slot < a.max_hits) {
+                BoostHit h;
+                h.snp_a = i;
+                h.snp_b = j;
+                h.measure = measure;
+                a.hits[slot] = h;
+            }
+        }
+        if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_xor(n_eval, off, 64);
+        if (!PRE) {
+            vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+            vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
+        }
+    }
+    if (lane == 0 && n_eval) {
+        atomicAdd(&a.tally[1], n_eval);
+        if (!PRE) {
+            atomicMax(&a.tally[2], ordered(vmax));
+            atomicMin(&a.tally[3], ordered(vmin));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Nine cells on 32 x 32 tiles: v_mfma_i32_16x16x64_i8 holds the vector issue port
+// for half of its 16 cycles, which leaves too little room for k_boost_mfma9's
+// expansion VALU (49 % of the matrix peak); v_mfma_i32_32x32x32_i8 holds it for a
+// quarter.  Nine 32 x 32 accumulator tiles are 144 registers -- one group at a
+// time: after the case planes the wave parks its 144 x 64 case counts in LDS as
+// uint16 (18 KiB per wave; used when the case group has < 65 536 members, else
+// k_boost_mfma9 runs) and re-uses the accumulators for the controls.  Everything
+// else as k_boost_mfma: 32 x 32 pairs per wave, operands expanded in registers.
+// ---------------------------------------------------------------------------
+template <bool PRE>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma9w(BoostArgs a) {
+    __shared__ uint32_t s_case[72 * 256];  // [pair of (cell, reg) halves][thread]: two uint16 case counts each
+
+    const uint32_t a0 = a.a_begin + blockIdx.y * MT, b0 = a.b_begin + blockIdx.x * MT;
+    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
+    if (a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t wy = wave >> 1, wx = wave & 1u;
+    const uint32_t fr = lane & 31u, fh = lane >> 5;
+
+    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;
+    const uint32_t snp_a = min(a0 + wy * 32u + fr, a_end - 1u), snp_b = min(b0 + wx * 32u + fr, b_end - 1u);
+    const u32x4 *ga = a.cct + ((uint64_t)(snp_a >> 6) * nchunk * 64u + (snp_a & 63u)) * 2u + fh;
+    const u32x4 *gb = a.cct + ((uint64_t)(snp_b >> 6) * nchunk * 64u + (snp_b & 63u)) * 2u + fh;
+
+    i32x16 acc[9];  // [3 * class of A + class of B], one group at a time
+    auto clear = [&]() {
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0;
+    };
+    clear();
+
+    constexpr int RING = 4;
+    u32x4 ua[RING], ub[RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+        ua[k] = ga[(uint64_t)k * 128u];
+        ub[k] = gb[(uint64_t)k * 128u];
+    }
+    const uint32_t last_chunk = nchunk - 1u;
+
+    auto chunk = [&](const u32x4 &va, const u32x4 &vb) {
+        uint32_t ca3[3][2], cb3[3][2], rb3[3][2];  // [class aa, ab, bb][word]
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            ca3[0][w] = va[w] & ~va[2 + w]; ca3[1][w] = va[2 + w] & ~va[w]; ca3[2][w] = va[w] & va[2 + w];
+            cb3[0][w] = vb[w] & ~vb[2 + w]; cb3[1][w] = vb[2 + w] & ~vb[w]; cb3[2][w] = vb[w] & vb[2 + w];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rb3[c][w] = __builtin_bswap32(__builtin_bitreverse32(cb3[c][w])) >> 1;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            i32x4 xa[3], yb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xa[c] = expand_a(ca3[c][s >> 1], s & 1);
+                yb[c] = expand_b(cb3[c][s >> 1], rb3[c][s >> 1], s & 1);
+            }
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y)
+                    acc[3 * x + y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[x], yb[y], acc[3 * x + y], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (32 cycles)
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // 4 VALU
+            }
+        }
+    };
+    auto round = [&](uint32_t c0) {
+        static_for<0, RING>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            chunk(ua[k], ub[k]);
+            const uint64_t nxt = (uint64_t)min(c0 + k + RING, last_chunk) * 128u;
+            ua[k] = ga[nxt];
+            ub[k] = gb[nxt];
+        });
+    };
+    for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
+    // park the case counts (each lane reads back only what it wrote: no barrier needed)
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            s_case[(c * 8 + (r >> 1)) * 256 + t] =
+                ((uint32_t)acc[c][r] >> 6) | (((uint32_t)acc[c][r + 1] >> 6) << 16);
+    clear();
+    for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
+
+    // ---- per pair (C layout as in k_boost_mfma)
+    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * 32u + 4u * fh;
+    const bool j_ok = j < b_end;
+    SnpMarginF mf2;
+    if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
+    const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
+    auto case_count = [&](int c, int r) {  // r may be a run-time value
+        const uint32_t v = s_case[(c * 8 + (r >> 1)) * 256 + t];
+        return (r & 1) ? v >> 16 : v & 0xFFFFu;
+    };
+
+    uint32_t need = 0;
+    unsigned long long n_eval = 0;
+    static_for<0, 16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+        if (i < a_end && j_ok && i < j) {
+            ++n_eval;
+            if (PRE) {
+                uint32_t ca[9], co[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    ca[c] = case_count(c, r);
+                    co[c] = (uint32_t)acc[c][r] >> 6;
+                }
+                const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n);
+                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
+                else if (!(bound < a.bound_threshold)) need |= 1u << r;
+            } else {
+                need |= 1u << r;
+            }
+        }
+    });
+
+    double vmax = -1.0e300, vmin = 1.0e300;
+    while (need) {
+        const int r = __ffs((int)need) - 1;
+        need &= need - 1u;
+        uint32_t ca[9], co[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            uint32_t y = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y = r == q ? (uint32_t)acc[c][q] : y;
+            ca[c] = case_count(c, r);
+            co[c] = y >> 6;
+        }
+        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+        const SnpMargin m1 = a.mar[i], m2 = a.mar[j];
+        const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+        if (!PRE) {
+            vmax = fmax(vmax, measure);
+            vmin = fmin(vmin, measure);
+        }
+        if (measure > a.threshold) {  // :482-484
+            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+            if (slot < a.max_hits) {
+                BoostHit h;
+                h.snp_a = i;
+                h.snp_b = j;
+                h.measure = measure;
+                a.hits[slot] = h;
+            }
+        }
+        if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_xor(n_eval, off, 64);
+        if (!PRE) {
+            vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+            vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
+        }
+    }
+    if (lane == 0 && n_eval) {
+        atomicAdd(&a.tally[1], n_eval);
+        if (!PRE) {
+            atomicMax(&a.tally[2], ordered(vmax));
+            atomicMin(&a.tally[3], ordered(vmin));
+        }
+    }
+}
+
 hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
                         const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
                         uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct) {
+                        float bound_threshold, const u32x4 *d_cct, bool narrow_tiles) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -757,6 +1129,18 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
         const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
         if (prefilter && d_marf) hipLaunchKernelGGL(k_boost_mfma<true>, mgrid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(k_boost_mfma<false>, mgrid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    if (d_cct && d_marf && wc * 32u < 65536u && !narrow_tiles) {  // missing calls: nine products per pair; case counts fit uint16
+        const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
+        if (prefilter) hipLaunchKernelGGL(k_boost_mfma9w<true>, mgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(k_boost_mfma9w<false>, mgrid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    if (d_cct && d_marf) {  // ... and any group size
+        const dim3 mgrid((n_b + M9B - 1) / M9B, (n_a + M9A - 1) / M9A);
+        if (prefilter) hipLaunchKernelGGL(k_boost_mfma9<true>, mgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(k_boost_mfma9<false>, mgrid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
     const dim3 grid((n_b + TB - 1) / TB, (n_a + TA - 1) / TA);

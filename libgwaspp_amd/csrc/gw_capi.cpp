@@ -816,7 +816,7 @@ int ensure_selected(gw_table *t) {
     t->any_missing = false;
     for (uint64_t r = 0; r < m && !t->any_missing; ++r)
         t->any_missing = counts[r * 8 + 3] != 0 || counts[r * 8 + 7] != 0;
-    if (m && !t->any_missing) {  // the MFMA pair kernel reads a block-tiled copy
+    if (m) {  // the MFMA pair kernels read a block-tiled copy
         const size_t bytes = ((m + 63u) / 64u) * 64u * (size_t)((wc + wt) / 4u) * 32u;
         GW_HIP(hipMalloc((void **)&t->d_cct, bytes));
         GW_HIP(hipMemsetAsync(t->d_cct, 0, bytes, t->stream));
@@ -870,7 +870,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
                              (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
                              max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr,
-                             t->opt_boost_mfma ? t->d_cct : nullptr);
+                             t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
@@ -1016,7 +1016,8 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_complement = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES:
-        t->opt_boost_mfma = v ? 1 : 0;
+        if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_matrix_cores must be 0, 1 or 2");
+        t->opt_boost_mfma = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
@@ -1039,7 +1040,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
-    case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma && t->selected_valid && !t->any_missing; return GW_OK;
+    case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }
 }

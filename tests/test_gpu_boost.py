@@ -79,14 +79,19 @@ def test_boost_measures_vs_oracle(oracle, n, m, p_missing):
         # a capped list reports the full count
         few, n_hits2, *_ = t.boost_screen(0, m, 0, m, threshold=thr, max_hits=3)
         assert n_hits2 == n_hits and len(few) == min(3, n_hits)
-        # tables without a missing call take the int8-MFMA kernel by default: the vector-ALU kernel
-        # must give the same counts, hence bit-identical measures
-        assert t.get_option(gw.capi.OPT_BOOST_MATRIX_CORES) == (1 if p_missing == 0.0 else 0)
-        t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, 0)
-        again = t.boost_measures(0, m, 0, m)
-        assert np.array_equal(np.isnan(again), np.isnan(got)) and np.array_equal(again[ok_all := ~np.isnan(got)], got[ok_all])
-        blk2 = t.boost_measures(a0, na, b0, nb)
-        assert np.array_equal(blk2[~np.isnan(blk2)], blk[~np.isnan(blk)])
+        # the int8-MFMA kernels (4 products per pair without missing calls, 9 with) are the default: the
+        # vector-ALU kernel must give the same counts, hence bit-identical measures
+        assert t.get_option(gw.capi.OPT_BOOST_MATRIX_CORES) == 1
+        for mode in (0, 2):  # 0: vector ALU; 2: nine-cell tables on 16x16 MFMA tiles (the large-group fallback)
+            t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mode)
+            again = t.boost_measures(0, m, 0, m)
+            ok_all = ~np.isnan(got)
+            assert np.array_equal(np.isnan(again), np.isnan(got)) and np.array_equal(again[ok_all], got[ok_all])
+            blk2 = t.boost_measures(a0, na, b0, nb)
+            assert np.array_equal(blk2[~np.isnan(blk2)], blk[~np.isnan(blk)])
+            h2, n2, p2, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
+            assert (n2, p2) == (n_hits, n_pairs)
+            assert np.array_equal(np.sort(h2, order=["snp_a", "snp_b"]), np.sort(hits, order=["snp_a", "snp_b"]))
 
 
 @pytest.mark.parametrize("n", [70, 1000, 4097])
