@@ -934,20 +934,27 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma9(BoostArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Nine cells on 32 x 32 tiles: v_mfma_i32_16x16x64_i8 holds the vector issue port
-// for half of its 16 cycles, which leaves too little room for k_boost_mfma9's
-// expansion VALU (49 % of the matrix peak); v_mfma_i32_32x32x32_i8 holds it for a
-// quarter.  Nine 32 x 32 accumulator tiles are 144 registers -- one group at a
-// time: after the case planes the wave parks its 144 x 64 case counts in LDS as
-// uint16 (18 KiB per wave; used when the case group has < 65 536 members, else
-// k_boost_mfma9 runs) and re-uses the accumulators for the controls.  Everything
-// else as k_boost_mfma: 32 x 32 pairs per wave, operands expanded in registers.
+// One group at a time (k_boost_mfma_seq): the accumulators are the register budget
+// of these kernels, and half of them belong to the other group.  After the case
+// planes a wave parks its case counts in LDS as uint16 (each lane reads back only
+// what it wrote; used when the case group has < 65 536 members) and re-uses the
+// registers for the controls.  That buys
+//   NV = 3, TA = 1: all nine cells on 32 x 32 tiles (144 accumulators).  The
+//       16x16x64 MFMA of k_boost_mfma9 holds the vector issue port for half of its
+//       16 cycles, the 32x32x32 one for a quarter of its 32, and nine products
+//       share six operand expansions: 3.3 VALU per MFMA, 88 % of the matrix peak.
+//   NV = 2, TA = 2: the four corners on 64 x 32 pairs per wave (128 accumulators):
+//       six expansions per eight MFMAs instead of four per four.
+// Workgroup = 2 x 2 waves = (64 TA) x 64 pairs; everything else as k_boost_mfma.
 // ---------------------------------------------------------------------------
-template <bool PRE>
-__global__ void __launch_bounds__(256, 2) k_boost_mfma9w(BoostArgs a) {
-    __shared__ uint32_t s_case[72 * 256];  // [pair of (cell, reg) halves][thread]: two uint16 case counts each
+template <bool PRE, int NV, int TA>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma_seq(BoostArgs a) {
+    constexpr int NP = NV * NV;            // products per tile pair
+    constexpr int NT = TA * NP;            // accumulator tiles
+    constexpr int WA = 32 * TA;            // A rows per wave
+    __shared__ uint32_t s_case[NT * 8 * 256];  // [tile][register pair][thread]: two uint16 case counts
 
-    const uint32_t a0 = a.a_begin + blockIdx.y * MT, b0 = a.b_begin + blockIdx.x * MT;
+    const uint32_t a0 = a.a_begin + blockIdx.y * (2 * WA), b0 = a.b_begin + blockIdx.x * MT;
     const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
     if (a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;
 
@@ -956,54 +963,74 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma9w(BoostArgs a) {
     const uint32_t fr = lane & 31u, fh = lane >> 5;
 
     const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;
-    const uint32_t snp_a = min(a0 + wy * 32u + fr, a_end - 1u), snp_b = min(b0 + wx * 32u + fr, b_end - 1u);
-    const u32x4 *ga = a.cct + ((uint64_t)(snp_a >> 6) * nchunk * 64u + (snp_a & 63u)) * 2u + fh;
-    const u32x4 *gb = a.cct + ((uint64_t)(snp_b >> 6) * nchunk * 64u + (snp_b & 63u)) * 2u + fh;
+    auto unit = [&](uint32_t snp) {
+        return a.cct + ((uint64_t)(snp >> 6) * nchunk * 64u + (snp & 63u)) * 2u + fh;
+    };
+    const u32x4 *ga[TA];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) ga[ta] = unit(min(a0 + wy * WA + ta * 32u + fr, a_end - 1u));
+    const u32x4 *gb = unit(min(b0 + wx * 32u + fr, b_end - 1u));
 
-    i32x16 acc[9];  // [3 * class of A + class of B], one group at a time
+    i32x16 acc[TA][NP];  // [A tile][NV * class of A + class of B], one group at a time
     auto clear = [&]() {
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
+        for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0;
+            for (int c = 0; c < NP; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ta][c][r] = 0;
     };
     clear();
 
     constexpr int RING = 4;
-    u32x4 ua[RING], ub[RING];
+    u32x4 ua[RING][TA], ub[RING];
 #pragma unroll
     for (int k = 0; k < RING; ++k) {
-        ua[k] = ga[(uint64_t)k * 128u];
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) ua[k][ta] = ga[ta][(uint64_t)k * 128u];
         ub[k] = gb[(uint64_t)k * 128u];
     }
     const uint32_t last_chunk = nchunk - 1u;
 
-    auto chunk = [&](const u32x4 &va, const u32x4 &vb) {
-        uint32_t ca3[3][2], cb3[3][2], rb3[3][2];  // [class aa, ab, bb][word]
+    // class v of a row's word w: NV = 2: aa, bb; NV = 3: aa, ab, bb (plane0 = codes 1,3; plane1 = codes 2,3)
+    auto cls = [](const u32x4 &v, int c, int w) -> uint32_t {
+        const uint32_t p0 = v[w], p1 = v[2 + w];
+        if (c == 0) return p0 & ~p1;
+        if (c == NV - 1) return p0 & p1;
+        return p1 & ~p0;
+    };
+    auto chunk = [&](const u32x4 (&va)[TA], const u32x4 &vb) {
+        uint32_t ca[TA][NV][2], cb[NV][2], rb[NV][2];
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            ca3[0][w] = va[w] & ~va[2 + w]; ca3[1][w] = va[2 + w] & ~va[w]; ca3[2][w] = va[w] & va[2 + w];
-            cb3[0][w] = vb[w] & ~vb[2 + w]; cb3[1][w] = vb[2 + w] & ~vb[w]; cb3[2][w] = vb[w] & vb[2 + w];
+        for (int w = 0; w < 2; ++w)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rb3[c][w] = __builtin_bswap32(__builtin_bitreverse32(cb3[c][w])) >> 1;
-        }
+            for (int c = 0; c < NV; ++c) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            i32x4 xa[3], yb[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                xa[c] = expand_a(ca3[c][s >> 1], s & 1);
-                yb[c] = expand_b(cb3[c][s >> 1], rb3[c][s >> 1], s & 1);
+                for (int ta = 0; ta < TA; ++ta) ca[ta][c][w] = cls(va[ta], c, w);
+                cb[c][w] = cls(vb, c, w);
+                rb[c][w] = __builtin_bswap32(__builtin_bitreverse32(cb[c][w])) >> 1;
             }
 #pragma unroll
-            for (int x = 0; x < 3; ++x)
+        for (int s = 0; s < 4; ++s) {
+            i32x4 xa[TA][NV], yb[NV];
 #pragma unroll
-                for (int y = 0; y < 3; ++y)
-                    acc[3 * x + y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[x], yb[y], acc[3 * x + y], 0, 0, 0);
+            for (int c = 0; c < NV; ++c) {
 #pragma unroll
-            for (int m = 0; m < 9; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (32 cycles)
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // 4 VALU
+                for (int ta = 0; ta < TA; ++ta) xa[ta][c] = expand_a(ca[ta][c][s >> 1], s & 1);
+                yb[c] = expand_b(cb[c][s >> 1], rb[c][s >> 1], s & 1);
+            }
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                for (int x = 0; x < NV; ++x)
+#pragma unroll
+                    for (int y = 0; y < NV; ++y)
+                        acc[ta][NV * x + y] =
+                            __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[ta][x], yb[y], acc[ta][NV * x + y], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA (32 cycles)
+                __builtin_amdgcn_sched_group_barrier(0x002, NV == 3 ? 4 : 5, 0);  // its share of the VALU
             }
         }
     };
@@ -1011,71 +1038,102 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma9w(BoostArgs a) {
         static_for<0, RING>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             chunk(ua[k], ub[k]);
-            const uint64_t nxt = (uint64_t)min(c0 + k + RING, last_chunk) * 128u;
-            ua[k] = ga[nxt];
+            const uint64_t nxt = (uint64_t)min(c0 + k + RING, last_chunk) * 128u;  // past the end: re-read, unused
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) ua[k][ta] = ga[ta][nxt];
             ub[k] = gb[nxt];
         });
     };
     for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
-    // park the case counts (each lane reads back only what it wrote: no barrier needed)
 #pragma unroll
-    for (int c = 0; c < 9; ++c)
+    for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2)
-            s_case[(c * 8 + (r >> 1)) * 256 + t] =
-                ((uint32_t)acc[c][r] >> 6) | (((uint32_t)acc[c][r + 1] >> 6) << 16);
+        for (int c = 0; c < NP; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                s_case[((ta * NP + c) * 8 + (r >> 1)) * 256 + t] =
+                    ((uint32_t)acc[ta][c][r] >> 6) | (((uint32_t)acc[ta][c][r + 1] >> 6) << 16);  // products of 64
     clear();
     for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
 
-    // ---- per pair (C layout as in k_boost_mfma)
-    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * 32u + 4u * fh;
+    // ---- per pair (C layout as in k_boost_mfma); pair p = 16 ta + reg
+    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * WA + 4u * fh;
     const bool j_ok = j < b_end;
+    const SnpMargin *pm2 = a.mar + (j_ok ? j : b_end - 1u);
+    uint32_t f2c[3], f2t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f2c[k] = pm2->cases[k]; f2t[k] = pm2->ctrls[k]; }
     SnpMarginF mf2;
     if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
     const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
-    auto case_count = [&](int c, int r) {  // r may be a run-time value
-        const uint32_t v = s_case[(c * 8 + (r >> 1)) * 256 + t];
+    auto case_count = [&](int tile, int r) {  // r may be a run-time value
+        const uint32_t v = s_case[(tile * 8 + (r >> 1)) * 256 + t];
         return (r & 1) ? v >> 16 : v & 0xFFFFu;
+    };
+    auto row_of = [&](int p) { return i_base + (uint32_t)((p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2)); };
+    // the two 3 x 3 tables of a pair from its counted cells (cells[0] cases, [1] controls)
+    auto tables = [&](const uint32_t (&cells)[2][NP], const uint32_t *f1c, const uint32_t *f1t, uint32_t (&ca)[9],
+                      uint32_t (&co)[9]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint32_t *o = g == 0 ? ca : co;
+            if (NV == 3) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = cells[g][c % NP];
+            } else {  // table5.cpp:1088-1106 / 1125-1143: corners counted, the rest from the margins
+                const uint32_t *f1 = g == 0 ? f1c : f1t;
+                const uint32_t *f2 = g == 0 ? f2c : f2t;
+                o[0] = cells[g][0]; o[2] = cells[g][1]; o[6] = cells[g][2 % NP]; o[8] = cells[g][3 % NP];
+                o[1] = f1[0] - o[0] - o[2];
+                o[7] = f1[2] - o[8] - o[6];
+                o[3] = f2[0] - o[0] - o[6];
+                o[5] = f2[2] - o[2] - o[8];
+                o[4] = f2[1] - o[1] - o[7];
+            }
+        }
     };
 
     uint32_t need = 0;
     unsigned long long n_eval = 0;
-    static_for<0, 16>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+    static_for<0, 16 * TA>([&](auto pc) {
+        constexpr int p = decltype(pc)::value, ta = p >> 4, r = p & 15;
+        const uint32_t i = row_of(p);
         if (i < a_end && j_ok && i < j) {
             ++n_eval;
             if (PRE) {
-                uint32_t ca[9], co[9];
+                uint32_t cells[2][NP], ca[9], co[9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    ca[c] = case_count(c, r);
-                    co[c] = (uint32_t)acc[c][r] >> 6;
+                for (int c = 0; c < NP; ++c) {
+                    cells[0][c] = case_count(ta * NP + c, r);
+                    cells[1][c] = (uint32_t)acc[ta][c][r] >> 6;
                 }
+                const SnpMargin *pm1 = a.mar + i;
+                tables(cells, pm1->cases, pm1->ctrls, ca, co);
                 const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n);
                 if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
-                else if (!(bound < a.bound_threshold)) need |= 1u << r;
+                else if (!(bound < a.bound_threshold)) need |= 1u << p;
             } else {
-                need |= 1u << r;
+                need |= 1u << p;
             }
         }
     });
 
     double vmax = -1.0e300, vmin = 1.0e300;
     while (need) {
-        const int r = __ffs((int)need) - 1;
+        const int p = __ffs((int)need) - 1;
         need &= need - 1u;
-        uint32_t ca[9], co[9];
+        uint32_t cells[2][NP], ca[9], co[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
+        for (int c = 0; c < NP; ++c) {
             uint32_t y = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) y = r == q ? (uint32_t)acc[c][q] : y;
-            ca[c] = case_count(c, r);
-            co[c] = y >> 6;
+            for (int q = 0; q < 16 * TA; ++q) y = p == q ? (uint32_t)acc[q >> 4][c][q & 15] : y;
+            cells[0][c] = case_count((p >> 4) * NP + c, p & 15);
+            cells[1][c] = y >> 6;
         }
-        const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
-        const SnpMargin m1 = a.mar[i], m2 = a.mar[j];
+        const uint32_t i = row_of(p);
+        const SnpMargin m1 = a.mar[i], m2 = *pm2;
+        tables(cells, m1.cases, m1.ctrls, ca, co);
         const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
         if (!PRE) {
             vmax = fmax(vmax, measure);
@@ -1125,16 +1183,23 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
     a.marf = d_marf; a.bound_threshold = bound_threshold;
     a.cct = d_cct;
+    const bool small_case_group = wc * 32u < 65536u && !narrow_tiles;  // case counts fit uint16
+    if (d_cct && fast && small_case_group && d_marf) {  // four corners, 64 x 32 pairs per wave
+        const dim3 mgrid((n_b + MT - 1) / MT, (n_a + 2 * MT - 1) / (2 * MT));
+        if (prefilter) hipLaunchKernelGGL((k_boost_mfma_seq<true, 2, 2>), mgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_seq<false, 2, 2>), mgrid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     if (d_cct && fast) {
         const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
         if (prefilter && d_marf) hipLaunchKernelGGL(k_boost_mfma<true>, mgrid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(k_boost_mfma<false>, mgrid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
-    if (d_cct && d_marf && wc * 32u < 65536u && !narrow_tiles) {  // missing calls: nine products per pair; case counts fit uint16
+    if (d_cct && d_marf && small_case_group) {  // missing calls: nine products per pair
         const dim3 mgrid((n_b + MT - 1) / MT, (n_a + MT - 1) / MT);
-        if (prefilter) hipLaunchKernelGGL(k_boost_mfma9w<true>, mgrid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(k_boost_mfma9w<false>, mgrid, dim3(256), 0, stream, a);
+        if (prefilter) hipLaunchKernelGGL((k_boost_mfma_seq<true, 3, 1>), mgrid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_seq<false, 3, 1>), mgrid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
     if (d_cct && d_marf) {  // ... and any group size
