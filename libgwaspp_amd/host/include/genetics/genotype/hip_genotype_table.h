@@ -73,6 +73,10 @@ public:
                                          std::vector<uint> &cases, std::vector<uint> &ctrls);
     // getContingencyTable for many pairs in one launch; out = n x 16
     void getContingencyTables(const uint *pairs, size_t n_pairs, std::vector<uint> &tables);
+    // the post-select, margin-assisted getter (pairwise_marker_analyzable.h:185, table5.cpp:989-1150)
+    // for many pairs in one launch: computeGTest's tables (epistasis_func.cpp:508-704)
+    void getSelectedCaseControlContingencyTables(const uint *pairs, size_t n_pairs,
+                                                 std::vector<CONTIN_TABLE_T> &cases, std::vector<CONTIN_TABLE_T> &ctrls);
     // computeBoost's whole pre-screening loop (algorithms/epistasis_func.cpp:393-486) in one device
     // pass: pairs (i, j, measure) with measure > threshold, in the reference's (i, j) visiting order
     void boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing);

@@ -118,6 +118,24 @@ void gtestOnePair(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T &contin_
 
 void computeGTest(GenoTable &gt, marginal_information *pMargins, uint nIndivids,
                   std::vector<SNPInteractionPair> &passingThreshold, std::vector<double> &zval) {
+    if (HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt)) {
+        // the tables of all passing pairs in one device launch instead of one per pair
+        std::vector<uint> pairs;
+        pairs.reserve(2 * passingThreshold.size());
+        for (const SNPInteractionPair &p : passingThreshold) {
+            pairs.push_back(p.first.first);
+            pairs.push_back(p.first.second);
+        }
+        std::vector<CONTIN_TABLE_T> cases, ctrls;
+        hip->getSelectedCaseControlContingencyTables(pairs.data(), passingThreshold.size(), cases, ctrls);
+        for (size_t k = 0; k < passingThreshold.size(); ++k) {
+            SNPInteractionPair &p = passingThreshold[k];
+            double z;
+            gtestOnePair(cases[k], ctrls[k], pMargins[p.first.first], pMargins[p.first.second], nIndivids, p.second, z);
+            zval.push_back(z);
+        }
+        return;
+    }
     CaseControlContingencyTable ccct;
     for (SNPInteractionPair &p : passingThreshold) {
         const uint i = p.first.first, j = p.first.second;

@@ -299,6 +299,27 @@ void HipGenotypeTable::getContingencyTables(const uint *pairs, size_t n_pairs, s
     die_unless_ok(gw_pair_contingency(tbl, pairs, n_pairs, tables.data()), "gw_pair_contingency");
 }
 
+void HipGenotypeTable::getSelectedCaseControlContingencyTables(const uint *pairs, size_t n_pairs,
+                                                               std::vector<CONTIN_TABLE_T> &cases,
+                                                               std::vector<CONTIN_TABLE_T> &ctrls) {
+    if (!installed) std::abort();
+    std::vector<uint> cs(n_pairs * 16), ct(n_pairs * 16);
+    if (n_pairs)
+        die_unless_ok(gw_pair_case_control_contingency(tbl, pairs, n_pairs, cs.data(), ct.data()),
+                      "gw_pair_case_control_contingency");
+    cases.resize(n_pairs);
+    ctrls.resize(n_pairs);
+    for (size_t k = 0; k < n_pairs; ++k) {
+        for (int c = 0; c < 16; ++c) {
+            cases[k].contin[c] = cs[k * 16 + c];
+            ctrls[k].contin[c] = ct[k * 16 + c];
+        }
+        // exact tables: xx_xx = members missing at both markers (table5.cpp:1031,1062)
+        cases[k].xx_xx -= ref_words * 64u - nCaseCount;
+        ctrls[k].xx_xx -= ref_words * 64u - nControlCount;
+    }
+}
+
 void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing) {
     if (!installed) std::abort();
     passing.clear();
