@@ -265,6 +265,9 @@ typedef enum gw_option {
                                 products per pair when no call of the table is missing, nine otherwise)
                                 or AND + popcount on the vector ALU (0); 2 = as 1 but the nine-cell form
                                 always on 16x16 tiles (its fallback for case groups >= 65 536 members) */
+    GW_OPT_SHORT_ROWS = 10,  /* rows of at most 256 units (N <= 32 k) with every other shape option on auto:
+                                1 (default) several rows per wave at a time, masks in registers; 0 the
+                                row-at-a-time kernel; get returns whether the current table uses it */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

@@ -26,6 +26,7 @@ N_STATS = 8
 OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREADS, OPT_PIPELINE, OPT_COMPLEMENT = 1, 2, 3, 4, 5, 6, 7
 OPT_BOOST_PREFILTER = 8
 OPT_BOOST_MATRIX_CORES = 9
+OPT_SHORT_ROWS = 10
 
 
 class GwError(RuntimeError):

@@ -1,0 +1,139 @@
+// gw_boost_dev.h -- device-side pieces shared by the pair-path translation units
+// (gw_boost.hip, gw_boost_mfma.hip, gw_boost_seq4.hip, gw_boost_seq9.hip; split so that they compile in
+// parallel: the unrolled per-pair epilogues make each of them a minute of compile time).
+#pragma once
+#include <type_traits>
+
+#include "gw_kernels.h"
+
+namespace gw {
+
+
+// compile-time loop: the body sees its index as a constant
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+
+// order-preserving map double -> uint64 for atomicMax / atomicMin
+__device__ __forceinline__ unsigned long long ordered(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// computeBoost's measure for one pair from the two 3x3 tables
+// (epistasis_func.cpp:424-470); operation order as the oracle's gwo_boost_measure
+__device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                                const SnpMargin &m1, const SnpMargin &m2, int n,
+                                                const double *__restrict__ frac,
+                                                const double *__restrict__ xlogx) {
+    double tao = 0.0, im = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t x = ca[3 * a + b], y = co[3 * a + b];
+            const double pab = (double)(x + y) / (double)m2.margins[b];
+            const double t2 = (pab) * (m2.pbc[b]) * (m1.pca[a]);
+            const double t3 = (pab) * (m2.pbc[4 + b]) * (m1.pca[4 + a]);
+            tao += t2 + t3;
+            if (x > 0) {
+                const double t1 = frac[x];  // (double)x / n
+                im += xlogx[x];             // t1 * log(t1)
+                if (t2 > 0) im += -t1 * log(t2);
+            }
+            if (y > 0) {
+                const double t1 = frac[y];
+                im += xlogx[y];
+                if (t3 > 0) im += -t1 * log(t3);
+            }
+        }
+    }
+    return (im + log(tao)) * n * 2.0;
+}
+
+// The same quantity in single precision, arranged for one v_log_f32 per cell and group:
+//   measure = 2 * sum_cells [ x ln(r_case) + y ln(r_ctrl) ] + 2 n ln(tao),
+//   r = (k/n) / (pab * pbc * pca) = k / (x+y) / n * qb[b] * qa[a]
+// Its error against the FP64 measure stays far below the slack the caller subtracts from the
+// threshold (tests/test_gpu_boost.py measures it), so "bound < threshold - slack" proves that the
+// pair cannot pass; anything else (including NaN) is decided by the FP64 measure.
+__device__ __forceinline__ float boost_bound(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                             const SnpMarginF &f1, const SnpMarginF &f2, float n, float inv_n) {
+    float s = 0.0f, tao = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t x = ca[3 * a + b], y = co[3 * a + b];
+            const float fx = (float)x, fy = (float)y, fs = (float)(x + y);
+            const float rs = __builtin_amdgcn_rcpf(fs) * inv_n;
+            tao += fs * (f2.rb[b] * f1.pa[a] + f2.rb[3 + b] * f1.pa[3 + a]);
+            const float lx = fx * __log2f(fx * rs * (f2.qb[b] * f1.qa[a]));
+            const float ly = fy * __log2f(fy * rs * (f2.qb[3 + b] * f1.qa[3 + a]));
+            s += x ? lx : 0.0f;
+            s += y ? ly : 0.0f;
+        }
+    }
+    return 1.3862943611198906f * (s + n * __log2f(tao));  // 2 ln 2
+}
+
+struct BoostArgs {
+    const uint32_t *cc;
+    uint64_t cc_stride_w;
+    uint32_t wc, wt;
+    const SnpMargin *mar;
+    const double *frac, *xlogx;  // k/n and (k/n) log(k/n), k = 0 .. n
+    uint32_t a_begin, n_a, b_begin, n_b;
+    int n_individs;
+    double threshold;
+    BoostHit *hits;
+    unsigned long long max_hits;
+    unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
+    double *dense;              // n_a x n_b, or null
+    const SnpMarginF *marf;     // PRE only
+    const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
+    float bound_threshold;      // PRE: pairs whose FP32 bound is below this are not hits
+};
+
+
+// ---- operand expansion of the int8 MFMA kernels
+constexpr int MT = 64;  // SNPs per workgroup tile side
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+// Operand dword k (k = 0..7) of a 32-sample word = samples {k, 8+k, 16+k, 24+k}, one per byte: a single
+// v_and_b32 with 0x01010101 << k isolates them, leaving weight 2^k in every byte.  B takes the same
+// samples from the word with the bits of each byte reversed and shifted down by one, weight 2^(6-k):
+// every product is 64.  Bit 7 of a byte would be the int8 sign, so k = 7 is done with a shift
+// (A weight 1, B weight 64).  One fragment (step) = dwords 4hk .. 4hk+3 of one word.
+__device__ __forceinline__ i32x4 expand_a(uint32_t w, int hk) {
+    i32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * hk + e;
+        v[e] = k < 7 ? (int)(w & (0x01010101u << k)) : (int)((w >> 7) & 0x01010101u);
+    }
+    return v;
+}
+// rb = the B word with the bits of each byte reversed, >> 1 (bit 6-k of byte m = sample 8m+k, k <= 6)
+__device__ __forceinline__ i32x4 expand_b(uint32_t w, uint32_t rb, int hk) {
+    i32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * hk + e;
+        v[e] = k < 7 ? (int)(rb & (0x01010101u << (6 - k))) : (int)((w >> 1) & 0x40404040u);
+    }
+    return v;
+}
+
+// ---- per-file launchers behind launch_boost (grid and <PRE> chosen inside)
+hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);        // gw_boost.hip
+hipError_t launch_boost_mfma_both(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);   // gw_boost_mfma.hip
+hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq4.hip
+hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
+
+}  // namespace gw

@@ -1,0 +1,15 @@
+// gw_boost_seq4.hip -- k_boost_mfma_seq<PRE, 2, 2> (see gw_boost_seq.inc)
+#include "gw_boost_dev.h"
+
+namespace gw {
+
+#include "gw_boost_seq.inc"
+
+hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream) {
+    const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + 2 * MT - 1) / (2 * MT));
+    if (pre) hipLaunchKernelGGL((k_boost_mfma_seq<true, 2, 2>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_boost_mfma_seq<false, 2, 2>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace gw

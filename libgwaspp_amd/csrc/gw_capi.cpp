@@ -89,7 +89,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1;
 };
 
 namespace {
@@ -110,6 +110,7 @@ gw::ScanShape scan_shape(const gw_table *t) {
     //   masks do not fit (N > ~650 k): read through L2, 4 units in flight;
     //   short rows (N <= ~32 k): 256-thread workgroups, 8 per CU.
     gw::ScanShape sh{};
+    sh.compute_units = t->compute_units;
     sh.nontemporal = t->opt_nt;
     const bool want_lds = (t->opt_mask_lds < 0) ? true : (t->opt_mask_lds != 0);
     // single-mask kernel when the control mask is the complement of the case mask
@@ -153,6 +154,18 @@ gw::ScanShape scan_shape(const gw_table *t) {
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
     sh.grid_blocks = t->compute_units * per_cu;
+    // short rows with every shape option left on auto: several rows per wave at a time, masks in registers
+    if (short_rows && t->opt_short_rows && !t->opt_unroll && !t->opt_threads && t->opt_mask_lds < 0 && t->opt_pipeline < 0 &&
+        t->opt_nt && t->opt_complement != 2) {
+        sh.short_rows = 1;
+        sh.complement = 0;
+        sh.pipeline = 0;
+        sh.mask_in_lds = 0;
+        sh.lds_bytes = 0;
+        sh.unroll = 1;
+        sh.block_threads = 256;
+        sh.grid_blocks = t->compute_units * t->opt_blocks_per_cu;  // 0 = as many as the kernel's registers allow
+    }
     return sh;
 }
 
@@ -1019,6 +1032,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_matrix_cores must be 0, 1 or 2");
         t->opt_boost_mfma = (int)v;
         return GW_OK;
+    case GW_OPT_SHORT_ROWS:
+        t->opt_short_rows = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
         t->opt_prefilter = (int)v;
@@ -1040,6 +1056,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
+    case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }

@@ -33,7 +33,9 @@ struct ScanShape {
     int block_threads;  // 256/512/1024
     int complement;     // 1: control mask == ~case mask: single-mask kernel (k_scan_cc_compl)
     int pipeline;       // 1: continuous-stream kernel (k_scan_cc_pipe), 0: row-at-a-time (k_scan_cc)
-    int grid_blocks;    // persistent workgroups
+    int short_rows;     // 1: rows of <= 256 units, a sub-wave of 16 or 32 lanes per row (k_scan_cc_sub; 256 threads, no LDS)
+    int grid_blocks;    // persistent workgroups (k_scan_cc_sub: 0 = as many as fit)
+    int compute_units;
     size_t lds_bytes;
 };
 

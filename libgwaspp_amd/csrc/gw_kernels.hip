@@ -480,6 +480,157 @@ __global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 t
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
+// ---------------------------------------------------------------------------
+// Short rows (rows of at most 256 units, N <= 32 767).  With one wave per row the
+// scan is not memory- but instruction-bound there (PMC at N = 10 k: 11 % of the
+// wave cycles wait for memory, 160 VALU per row): a 79-unit row fills 62 % of its
+// two wave-steps, and every row pays six cross-lane reductions with lane reads into
+// SGPRs.  Here a row belongs to a SUB-WAVE of G = 16 or 32 lanes:
+//   * the wave works on 64/G consecutive rows at once (ceil(units/G) steps, 99 % of
+//     the lane slots carry data at N = 10 k), all loads of a batch issued before the
+//     first popcount and the next batch's already in flight (two register buffers);
+//   * a 16-lane group is a DPP row: four v_add_dpp leave the row's sum in every lane
+//     of the group (G = 32: one more row_bcast:15 add, sums in the upper halves) --
+//     no lane reads, no scalar adds;
+//   * batch p of a wave parks its results in lane p of each group, so the 64 (32)
+//     parked rows of the FP64 epilogue fill up without moving anything across lanes;
+//   * masks live in registers (no LDS, no barrier); lanes past the row end re-read
+//     its last unit against a zero mask, so no load is conditional;
+//   * with N < 65 536 two counters share a register through the reduction, and the
+//     popcounts accumulate in v_bcnt's own add operand.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bcnt_acc(uint32_t &c, uint32_t x) {
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c) : "v"(x));
+}
+__device__ __forceinline__ void acc_unit_chain(const u32x4 a, const u32x4 b, const u32x4 mc, const u32x4 mt,
+                                               uint32_t (&c)[6]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = a[k] & mc[k], y = b[k] & mc[k];
+        bcnt_acc(c[0], x);
+        bcnt_acc(c[1], y);
+        bcnt_acc(c[2], x & y);
+        x = a[k] & mt[k];
+        y = b[k] & mt[k];
+        bcnt_acc(c[3], x);
+        bcnt_acc(c[4], y);
+        bcnt_acc(c[5], x & y);
+    }
+}
+// sum over each 16-lane DPP row, result in all of its lanes
+__device__ __forceinline__ uint32_t row16_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return v;
+}
+
+template <int G, int STEPS, bool PACK>
+__global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
+    static_assert(G == 16 || G == 32, "sub-wave of 16 or 32 lanes per row");
+    constexpr uint32_t RW = 64 / G;  // rows per wave and batch
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t grp = lane / G, li = lane % G;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const uint32_t last_unit = a.units - 1u;
+
+    u32x4 mc[STEPS], mt[STEPS];
+    uint32_t uidx[STEPS];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const uint32_t u = (uint32_t)G * k + li;
+        uidx[k] = min(u, last_unit);
+        const u32x4 zero = {0, 0, 0, 0};
+        mc[k] = u <= last_unit ? a.case_mask[u] : zero;
+        mt[k] = u <= last_unit ? a.ctrl_mask[u] : zero;
+    }
+
+    // parked results: batch p of this wave -> lane p of every group (G = 32: of its upper half)
+    uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t my_row = 0xFFFFFFFFu, slot = 0;
+    const uint32_t park_lane = (G == 16) ? li : li - 16u;  // 0..15 in the lanes that hold the sums
+    const bool holds_sum = G == 16 || li >= 16u;
+    const uint32_t n_batches = (a.n_rows + RW - 1u) / RW, last_row = a.n_rows - 1u;
+
+    auto issue = [&](u32x4 (&A)[STEPS], u32x4 (&B)[STEPS], uint32_t b) {
+        const uint32_t row = min(b * RW + grp, last_row);  // past the end: the last row again, result dropped
+        const u32x4 *p0 = a.table + (a.row_begin + row) * a.row_stride_u;
+        const u32x4 *p1 = p0 + a.plane_stride_u;
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) {
+            A[k] = ld_stream<true>(p0 + uidx[k]);
+            B[k] = ld_stream<true>(p1 + uidx[k]);
+        }
+    };
+    auto consume = [&](const u32x4 (&A)[STEPS], const u32x4 (&B)[STEPS], uint32_t b) {
+        uint32_t c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) acc_unit_chain(A[k], B[k], mc[k], mt[k], c);
+        constexpr int NRED = PACK ? 3 : 6;
+        uint32_t tot[NRED];
+#pragma unroll
+        for (int j = 0; j < NRED; ++j) {
+            uint32_t v = row16_sum_dpp(PACK ? (c[j] | (c[3 + j] << 16)) : c[j]);  // packed halves < 65 536
+            if (G == 32)  // lanes 16-31 / 48-63 += lane 15 / 47: the 32-lane sum
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+            tot[j] = v;
+        }
+        const uint32_t row = b * RW + grp;
+        const bool park = holds_sum && park_lane == slot && row < a.n_rows;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            mine[j] = park ? (PACK ? (tot[j] & 0xFFFFu) : tot[j]) : mine[j];
+            mine[3 + j] = park ? (PACK ? (tot[j] >> 16) : tot[(3 + j) % NRED]) : mine[3 + j];
+        }
+        my_row = park ? row : my_row;
+        if (++slot == 16u) {
+            if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
+            my_row = 0xFFFFFFFFu;
+            slot = 0;
+        }
+    };
+
+    uint32_t b = gwave;
+    if (b < n_batches) {
+        u32x4 A0[STEPS], B0[STEPS], A1[STEPS], B1[STEPS];
+        issue(A0, B0, b);
+        for (;;) {
+            issue(A1, B1, b + total_waves);
+            consume(A0, B0, b);
+            b += total_waves;
+            if (b >= n_batches) break;
+            issue(A0, B0, b + total_waves);
+            consume(A1, B1, b);
+            b += total_waves;
+            if (b >= n_batches) break;
+        }
+    }
+    if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
+}
+
+template <int G, int STEPS, bool PACK>
+static hipError_t launch_scan_sub_p(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
+    int grid = sh.grid_blocks;
+    if (grid <= 0) {  // auto: as many persistent workgroups as the registers let a CU hold
+        static int resident = 0;
+        if (!resident) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_cc_sub<G, STEPS, PACK>, 256, 0) != hipSuccess || n < 1) n = 2;
+            resident = n > 8 ? 8 : n;
+        }
+        grid = sh.compute_units * resident;
+    }
+    hipLaunchKernelGGL((k_scan_cc_sub<G, STEPS, PACK>), dim3(grid), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+template <int G, int STEPS>
+static hipError_t launch_scan_sub(const ScanArgs &args, const ScanShape &sh, bool pack, hipStream_t stream) {
+    return pack ? launch_scan_sub_p<G, STEPS, true>(args, sh, stream) : launch_scan_sub_p<G, STEPS, false>(args, sh, stream);
+}
+
 template <int UNROLL, bool MASK_LDS, bool NT>
 static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
     if (sh.pipeline && UNROLL <= 4)
@@ -519,6 +670,27 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
     a.ctrl_count = ctrl_count;
     a.counts = d_counts;
     a.stats = d_stats;
+    if (sh.short_rows) {  // rows of at most 256 units: a sub-wave of 16 (<= 128 units) or 32 lanes per row
+        const bool pack = tv.n_samples < 65536u;
+        if (tv.units <= 128u) {
+            switch ((tv.units + 15u) / 16u) {
+            case 1: return launch_scan_sub<16, 1>(a, sh, pack, stream);
+            case 2: return launch_scan_sub<16, 2>(a, sh, pack, stream);
+            case 3: return launch_scan_sub<16, 3>(a, sh, pack, stream);
+            case 4: return launch_scan_sub<16, 4>(a, sh, pack, stream);
+            case 5: return launch_scan_sub<16, 5>(a, sh, pack, stream);
+            case 6: return launch_scan_sub<16, 6>(a, sh, pack, stream);
+            case 7: return launch_scan_sub<16, 7>(a, sh, pack, stream);
+            default: return launch_scan_sub<16, 8>(a, sh, pack, stream);
+            }
+        }
+        switch ((tv.units + 31u) / 32u) {
+        case 5: return launch_scan_sub<32, 5>(a, sh, pack, stream);
+        case 6: return launch_scan_sub<32, 6>(a, sh, pack, stream);
+        case 7: return launch_scan_sub<32, 7>(a, sh, pack, stream);
+        default: return launch_scan_sub<32, 8>(a, sh, pack, stream);
+        }
+    }
     if (sh.complement) {
         switch (sh.unroll) {
         case 1: hipLaunchKernelGGL((k_scan_cc_compl<1>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;

@@ -426,3 +426,42 @@ def test_allocation_failure_is_reported_not_fatal():
     assert e.value.code == -3, str(e.value)
     with gw.GwTable(1000, 10) as t:      # still works afterwards
         assert t.scan_distribution().shape == (10, 4)
+
+
+@pytest.mark.parametrize("n,m", [(70, 9), (1000, 777), (8191, 130), (8193, 131), (16400, 257), (24576, 66), (24700, 67),
+                                 (32767, 50), (32768, 50)])
+def test_short_row_kernel(oracle, n, m):
+    """Rows of at most 256 units (N <= 32 767) go through k_scan_cc_short by default -- several rows per
+    wave at a time, masks in registers, packed reductions: same counts and statistics as the oracle and
+    as the row-at-a-time kernel, for every step count (1..4), ragged row counts and sub-ranges."""
+    rng = np.random.default_rng(n * 7 + m)
+    codes = _random_codes(rng, m, n, p_missing=0.03)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    ts = oracle.pack_codes(codes, "stream")
+    want_counts, want_stats = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs, ct, nc, nt)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        assert t.get_option(capi.OPT_SHORT_ROWS) == (1 if n <= 32767 else 0)
+        counts, stats = t.scan_case_control()
+        assert np.array_equal(counts, want_counts)
+        _assert_stats(stats, want_stats)
+        if m > 9:
+            c2, s2 = t.scan_case_control(5, m - 9)
+            assert np.array_equal(c2, want_counts[5:m - 4]) and np.array_equal(s2, stats[5:m - 4])
+        c1, _ = t.scan_case_control(m - 1, 1)
+        assert np.array_equal(c1, want_counts[m - 1:])
+        t.set_option(capi.OPT_SHORT_ROWS, 0)
+        assert t.get_option(capi.OPT_SHORT_ROWS) == 0
+        c3, s3 = t.scan_case_control()
+        assert np.array_equal(c3, counts) and np.array_equal(s3, stats)
+        # everyone a case / nobody a control: counts reach the 16-bit boundary of the packed reduction
+        everyone = np.arange(n, dtype=np.int32)
+        _, cs_all, nc_all = oracle.ccs_masks(everyone, n)
+        _, ct_none, nt_none = oracle.ccs_masks(np.zeros(0, np.int32), n)
+        t.set_option(capi.OPT_SHORT_ROWS, 1)
+        t.set_case_control(cs_all, ct_none, nc_all, nt_none)
+        want_c, want_s = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs_all, ct_none, nc_all, nt_none)
+        c4, s4 = t.scan_case_control()
+        assert np.array_equal(c4, want_c)
+        _assert_stats(s4, want_s)

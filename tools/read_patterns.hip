@@ -116,6 +116,40 @@ __global__ void v_wave_row_blocked(const u32x4 *t, uint64_t stride, uint32_t pst
     sink_acc(acc, sink);
 }
 
+// V5: a sub-wave of G lanes per row (64/G consecutive rows per wave at a time), S steps per row, the next
+// batch's loads issued before the current one is consumed (the short-row scan's traversal)
+template <int G, int S>
+__global__ void v_subwave(const u32x4 *t, uint64_t stride, uint32_t pstride, uint32_t units, uint32_t rows, uint32_t *sink) {
+    constexpr uint32_t RW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6, grp = lane / G, li = lane % G;
+    const uint32_t g = blockIdx.x * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tw = gridDim.x * wpb;
+    const uint32_t nb = (rows + RW - 1) / RW, last = units - 1;
+    uint32_t ui[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) ui[k] = min((uint32_t)G * k + li, last);
+    u32x4 acc = {0, 0, 0, 0};
+    auto issue = [&](u32x4 (&A)[S], u32x4 (&B)[S], uint32_t b) {
+        const uint32_t r = min(b * RW + grp, rows - 1);
+        const u32x4 *p0 = t + (uint64_t)r * stride, *p1 = p0 + pstride;
+#pragma unroll
+        for (int k = 0; k < S; ++k) { A[k] = ldnt(p0 + ui[k]); B[k] = ldnt(p1 + ui[k]); }
+    };
+    auto eat = [&](u32x4 (&A)[S], u32x4 (&B)[S]) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) acc ^= A[k] ^ B[k];
+    };
+    uint32_t b = g;
+    if (b < nb) {
+        u32x4 A0[S], B0[S], A1[S], B1[S];
+        issue(A0, B0, b);
+        for (;;) {
+            issue(A1, B1, b + tw); eat(A0, B0); b += tw; if (b >= nb) break;
+            issue(A0, B0, b + tw); eat(A1, B1); b += tw; if (b >= nb) break;
+        }
+    }
+    sink_acc(acc, sink);
+}
+
 template <typename F>
 static double time_ms(F launch, int reps) {
     hipEvent_t a, b;
@@ -171,6 +205,13 @@ int main(int argc, char **argv) {
     report("V3 flat grid-stride, 512thr x1", time_ms([&] { hipLaunchKernelGGL(v_flat, dim3(cus), dim3(512), 0, 0, t, total_units, sink); }, 5), total_units * 16.0);
     report("V3 flat grid-stride, 1024thr x2", time_ms([&] { hipLaunchKernelGGL(v_flat, dim3(cus * 2), dim3(1024), 0, 0, t, total_units, sink); }, 5), total_units * 16.0);
     report("V3 flat grid-stride, 256thr x8", time_ms([&] { hipLaunchKernelGGL(v_flat, dim3(cus * 8), dim3(256), 0, 0, t, total_units, sink); }, 5), total_units * 16.0);
+    if (units <= 80) {
+        RUN("V5 sub-wave 16 lanes/row, 5 steps, 256thr x2", (v_subwave<16, 5>), cus * 2, 256, t, stride, pstride, units, rows, sink);
+        RUN("V5 sub-wave 16 lanes/row, 5 steps, 256thr x4", (v_subwave<16, 5>), cus * 4, 256, t, stride, pstride, units, rows, sink);
+        RUN("V5 sub-wave 16 lanes/row, 5 steps, 256thr x8", (v_subwave<16, 5>), cus * 8, 256, t, stride, pstride, units, rows, sink);
+        RUN("V5 sub-wave 32 lanes/row, 3 steps, 256thr x4", (v_subwave<32, 3>), cus * 4, 256, t, stride, pstride, units, rows, sink);
+        RUN("V5 sub-wave 32 lanes/row, 3 steps, 256thr x8", (v_subwave<32, 3>), cus * 8, 256, t, stride, pstride, units, rows, sink);
+    }
     CK(hipFree(t));
     CK(hipFree(sink));
     return 0;

@@ -20,6 +20,7 @@ from bench import WORKLOADS, SEED  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--snps", type=int, default=0)
+ap.add_argument("--samples", type=int, default=0, help="with --snps: a table of this size instead of a named workload")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--unroll", default="2,4,8")
@@ -36,6 +37,8 @@ EXTRA = {"n250k": (250_000, 400_000, ""), "n50k": (50_000, 1_000_000, ""), "n1m"
 n, m, _ = {**WORKLOADS, **EXTRA}[args.workload]
 if args.snps:
     m = args.snps
+if args.samples:
+    n = args.samples
 t = gw.GwTable(n, m)
 t.simulate(SEED, 0, 0)
 t.simulate_phenotype(SEED)
