@@ -490,9 +490,9 @@ __global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 t
 //     the lane slots carry data at N = 10 k), all loads of a batch issued before the
 //     first popcount and the next batch's already in flight (two register buffers);
 //   * a 16-lane group is a DPP row: four v_add_dpp leave the row's sum in every lane
-//     of the group (G = 32: one more row_bcast:15 add, sums in the upper halves) --
-//     no lane reads, no scalar adds;
-//   * batch p of a wave parks its results in lane p of each group, so the 64 (32)
+//     of the group (G = 32: one ds_swizzle adds the other half) -- no lane reads,
+//     no scalar adds;
+//   * batch p of a wave parks its results in lane p of each group, so the 64
 //     parked rows of the FP64 epilogue fill up without moving anything across lanes;
 //   * masks live in registers (no LDS, no barrier); lanes past the row end re-read
 //     its last unit against a zero mask, so no load is conditional;
@@ -548,11 +548,9 @@ __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
         mt[k] = u <= last_unit ? a.ctrl_mask[u] : zero;
     }
 
-    // parked results: batch p of this wave -> lane p of every group (G = 32: of its upper half)
+    // parked results: batch p of this wave -> lane p of every group (all 64 lanes fill up in G batches)
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
     uint32_t my_row = 0xFFFFFFFFu, slot = 0;
-    const uint32_t park_lane = (G == 16) ? li : li - 16u;  // 0..15 in the lanes that hold the sums
-    const bool holds_sum = G == 16 || li >= 16u;
     const uint32_t n_batches = (a.n_rows + RW - 1u) / RW, last_row = a.n_rows - 1u;
 
     auto issue = [&](u32x4 (&A)[STEPS], u32x4 (&B)[STEPS], uint32_t b) {
@@ -574,19 +572,19 @@ __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
 #pragma unroll
         for (int j = 0; j < NRED; ++j) {
             uint32_t v = row16_sum_dpp(PACK ? (c[j] | (c[3 + j] << 16)) : c[j]);  // packed halves < 65 536
-            if (G == 32)  // lanes 16-31 / 48-63 += lane 15 / 47: the 32-lane sum
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+            if (G == 32)  // + the other 16-lane half of the group (lane ^ 16, through the LDS crossbar): all 32 lanes
+                v += (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);  // bit mode: and 0x1f, or 0, xor 0x10
             tot[j] = v;
         }
         const uint32_t row = b * RW + grp;
-        const bool park = holds_sum && park_lane == slot && row < a.n_rows;
+        const bool park = li == slot && row < a.n_rows;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             mine[j] = park ? (PACK ? (tot[j] & 0xFFFFu) : tot[j]) : mine[j];
             mine[3 + j] = park ? (PACK ? (tot[j] >> 16) : tot[(3 + j) % NRED]) : mine[3 + j];
         }
         my_row = park ? row : my_row;
-        if (++slot == 16u) {
+        if (++slot == (uint32_t)G) {
             if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
             my_row = 0xFFFFFFFFu;
             slot = 0;
@@ -670,21 +668,20 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
     a.ctrl_count = ctrl_count;
     a.counts = d_counts;
     a.stats = d_stats;
-    if (sh.short_rows) {  // rows of at most 256 units: a sub-wave of 16 (<= 128 units) or 32 lanes per row
+    if (sh.short_rows) {  // rows of at most 256 units: a sub-wave of 16 (<= 80 units) or 32 lanes per row
         const bool pack = tv.n_samples < 65536u;
-        if (tv.units <= 128u) {
+        if (tv.units <= 80u) {  // at most 5 steps of 16 lanes
             switch ((tv.units + 15u) / 16u) {
             case 1: return launch_scan_sub<16, 1>(a, sh, pack, stream);
             case 2: return launch_scan_sub<16, 2>(a, sh, pack, stream);
             case 3: return launch_scan_sub<16, 3>(a, sh, pack, stream);
             case 4: return launch_scan_sub<16, 4>(a, sh, pack, stream);
-            case 5: return launch_scan_sub<16, 5>(a, sh, pack, stream);
-            case 6: return launch_scan_sub<16, 6>(a, sh, pack, stream);
-            case 7: return launch_scan_sub<16, 7>(a, sh, pack, stream);
-            default: return launch_scan_sub<16, 8>(a, sh, pack, stream);
+            default: return launch_scan_sub<16, 5>(a, sh, pack, stream);
             }
         }
         switch ((tv.units + 31u) / 32u) {
+        case 3: return launch_scan_sub<32, 3>(a, sh, pack, stream);
+        case 4: return launch_scan_sub<32, 4>(a, sh, pack, stream);
         case 5: return launch_scan_sub<32, 5>(a, sh, pack, stream);
         case 6: return launch_scan_sub<32, 6>(a, sh, pack, stream);
         case 7: return launch_scan_sub<32, 7>(a, sh, pack, stream);
