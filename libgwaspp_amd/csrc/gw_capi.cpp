@@ -675,7 +675,7 @@ int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     // 512-thread workgroups: one per CU for long rows (few, fat streams), more for short ones
     const int per_cu = t->tv.units <= 256u ? 4 : (t->tv.units < 2000u ? 2 : 1);
     GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, t->compute_units * per_cu,
-                                pick_stream(t, hip_stream)));
+                                pick_stream(t, hip_stream), t->opt_short_rows ? t->compute_units : 0));
     return GW_OK;
 }
 

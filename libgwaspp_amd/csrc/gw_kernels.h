@@ -49,7 +49,9 @@ hipError_t prepare_scan_kernels(size_t max_lds_bytes);
 
 // plain distribution: dist[n_rows][4] = aa,ab,bb,xx(exact)
 hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
-                            uint32_t *d_dist, int grid_blocks, hipStream_t stream);
+                            uint32_t *d_dist, int grid_blocks, hipStream_t stream,
+                            // > 0 (the CU count): rows of <= 256 units take the sub-wave kernel (k_scan_dist_sub)
+                            int short_rows_cus = 0);
 
 // pair contingency: pairs[n][2] (row indices), out[n][16]; with masks:
 // out_case/out_ctrl (mask ANDed before decoding, table5.cpp:823-829)

@@ -787,9 +787,135 @@ __global__ void __launch_bounds__(1024) k_scan_dist(const u32x4 *table, uint64_t
     }
 }
 
+// Short rows: the sub-wave traversal of k_scan_cc_sub without masks (three counters; packed two and one
+// through the reduction when N < 65 536).  Lanes past the row end re-read its last unit and are
+// switched off by a per-lane factor instead of a mask.
+template <int G, int STEPS>
+__global__ void __launch_bounds__(256) k_scan_dist_sub(const u32x4 *table, uint64_t row_stride_u,
+                                                       uint32_t plane_stride_u, uint32_t units, uint32_t n_samples,
+                                                       uint64_t row_begin, uint32_t n_rows, uint32_t *dist) {
+    constexpr uint32_t RW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63u, grp = lane / G, li = lane % G;
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const uint32_t last_unit = units - 1u, last_row = n_rows - 1u, n_batches = (n_rows + RW - 1u) / RW;
+    uint32_t uidx[STEPS], live[STEPS];  // live: all ones where the lane's unit exists
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+        const uint32_t u = (uint32_t)G * k + li;
+        uidx[k] = min(u, last_unit);
+        live[k] = u <= last_unit ? 0xFFFFFFFFu : 0u;
+    }
+    uint32_t mine[3] = {0, 0, 0}, my_row = 0xFFFFFFFFu, slot = 0;
+    auto flush = [&]() {
+        if (my_row != 0xFFFFFFFFu) {
+            const uint32_t aa = mine[0] - mine[2], ab = mine[1] - mine[2], bb = mine[2];
+            u32x4 v = {aa, ab, bb, n_samples - aa - ab - bb};
+            *reinterpret_cast<u32x4 *>(dist + (size_t)my_row * 4u) = v;
+        }
+        my_row = 0xFFFFFFFFu;
+        slot = 0;
+    };
+    auto issue = [&](u32x4 (&A)[STEPS], u32x4 (&B)[STEPS], uint32_t b) {
+        const uint32_t row = min(b * RW + grp, last_row);
+        const u32x4 *p0 = table + (row_begin + row) * row_stride_u;
+        const u32x4 *p1 = p0 + plane_stride_u;
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) {
+            A[k] = ld_stream<true>(p0 + uidx[k]);
+            B[k] = ld_stream<true>(p1 + uidx[k]);
+        }
+    };
+    auto consume = [&](const u32x4 (&A)[STEPS], const u32x4 (&B)[STEPS], uint32_t b) {
+        uint32_t c[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t x = A[k][j] & live[k], y = B[k][j] & live[k];
+                bcnt_acc(c[0], x);
+                bcnt_acc(c[1], y);
+                bcnt_acc(c[2], x & y);
+            }
+        auto group_sum = [](uint32_t v) {
+            v = row16_sum_dpp(v);
+            if (G == 32) v += (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);  // + the other half (lane ^ 16)
+            return v;
+        };
+        uint32_t t0, t1;
+        if (n_samples < 65536u) {  // wave-uniform: two counters share a register through the reduction
+            const uint32_t t01 = group_sum(c[0] | (c[1] << 16));
+            t0 = t01 & 0xFFFFu;
+            t1 = t01 >> 16;
+        } else {
+            t0 = group_sum(c[0]);
+            t1 = group_sum(c[1]);
+        }
+        const uint32_t t2 = group_sum(c[2]);
+        const uint32_t row = b * RW + grp;
+        const bool park = li == slot && row < n_rows;
+        mine[0] = park ? t0 : mine[0];
+        mine[1] = park ? t1 : mine[1];
+        mine[2] = park ? t2 : mine[2];
+        my_row = park ? row : my_row;
+        if (++slot == (uint32_t)G) flush();
+    };
+    uint32_t b = gwave;
+    if (b < n_batches) {
+        u32x4 A0[STEPS], B0[STEPS], A1[STEPS], B1[STEPS];
+        issue(A0, B0, b);
+        for (;;) {
+            issue(A1, B1, b + total_waves);
+            consume(A0, B0, b);
+            b += total_waves;
+            if (b >= n_batches) break;
+            issue(A0, B0, b + total_waves);
+            consume(A1, B1, b);
+            b += total_waves;
+            if (b >= n_batches) break;
+        }
+    }
+    flush();
+}
+
+template <int G, int STEPS>
+static hipError_t launch_scan_dist_sub(const TableView &tv, uint64_t row_begin, uint32_t n_rows, uint32_t *d_dist,
+                                       int compute_units, hipStream_t stream) {
+    static int resident = 0;
+    if (!resident) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_dist_sub<G, STEPS>, 256, 0) != hipSuccess || n < 1) n = 2;
+        resident = n > 8 ? 8 : n;
+    }
+    hipLaunchKernelGGL((k_scan_dist_sub<G, STEPS>), dim3(compute_units * resident), dim3(256), 0, stream, tv.base,
+                       tv.row_stride_u, tv.plane_stride_u, tv.units, tv.n_samples, row_begin, n_rows, d_dist);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_rows,
-                            uint32_t *d_dist, int grid_blocks, hipStream_t stream) {
+                            uint32_t *d_dist, int grid_blocks, hipStream_t stream, int short_rows_cus) {
     if (n_rows == 0) return hipSuccess;
+    if (short_rows_cus > 0 && tv.units <= 256u) {
+        const int cu = short_rows_cus;
+        if (tv.units <= 80u) {
+            switch ((tv.units + 15u) / 16u) {
+            case 1: return launch_scan_dist_sub<16, 1>(tv, row_begin, n_rows, d_dist, cu, stream);
+            case 2: return launch_scan_dist_sub<16, 2>(tv, row_begin, n_rows, d_dist, cu, stream);
+            case 3: return launch_scan_dist_sub<16, 3>(tv, row_begin, n_rows, d_dist, cu, stream);
+            case 4: return launch_scan_dist_sub<16, 4>(tv, row_begin, n_rows, d_dist, cu, stream);
+            default: return launch_scan_dist_sub<16, 5>(tv, row_begin, n_rows, d_dist, cu, stream);
+            }
+        }
+        switch ((tv.units + 31u) / 32u) {
+        case 3: return launch_scan_dist_sub<32, 3>(tv, row_begin, n_rows, d_dist, cu, stream);
+        case 4: return launch_scan_dist_sub<32, 4>(tv, row_begin, n_rows, d_dist, cu, stream);
+        case 5: return launch_scan_dist_sub<32, 5>(tv, row_begin, n_rows, d_dist, cu, stream);
+        case 6: return launch_scan_dist_sub<32, 6>(tv, row_begin, n_rows, d_dist, cu, stream);
+        case 7: return launch_scan_dist_sub<32, 7>(tv, row_begin, n_rows, d_dist, cu, stream);
+        default: return launch_scan_dist_sub<32, 8>(tv, row_begin, n_rows, d_dist, cu, stream);
+        }
+    }
     hipLaunchKernelGGL(k_scan_dist, dim3(grid_blocks), dim3(512), 0, stream, tv.base,
                        tv.row_stride_u, tv.plane_stride_u, tv.units, tv.n_samples, row_begin,
                        n_rows, d_dist);

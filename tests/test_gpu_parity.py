@@ -451,10 +451,19 @@ def test_short_row_kernel(oracle, n, m):
             assert np.array_equal(c2, want_counts[5:m - 4]) and np.array_equal(s2, stats[5:m - 4])
         c1, _ = t.scan_case_control(m - 1, 1)
         assert np.array_equal(c1, want_counts[m - 1:])
+        # the plain distribution takes the same traversal (k_scan_dist_sub): exact counts incl. missing
+        gs = oracle.geometry_stream(n)
+        want_dist = np.array([(lambda d: (d[0], d[1], d[2], n - d[0] - d[1] - d[2]))(oracle.stream_dist(ts[r], gs))
+                              for r in range(m)], dtype=np.uint32)
+        dist = t.scan_distribution()
+        assert np.array_equal(dist, want_dist)
+        if m > 9:
+            assert np.array_equal(t.scan_distribution(5, m - 9), want_dist[5:m - 4])
         t.set_option(capi.OPT_SHORT_ROWS, 0)
         assert t.get_option(capi.OPT_SHORT_ROWS) == 0
         c3, s3 = t.scan_case_control()
         assert np.array_equal(c3, counts) and np.array_equal(s3, stats)
+        assert np.array_equal(t.scan_distribution(), want_dist)
         # everyone a case / nobody a control: counts reach the 16-bit boundary of the packed reduction
         everyone = np.arange(n, dtype=np.int32)
         _, cs_all, nc_all = oracle.ccs_masks(everyone, n)

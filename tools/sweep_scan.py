@@ -75,4 +75,15 @@ print("unroll thr perCU lds nt pipe compl | median ms | min ms | GB/s(min) | %pe
 for c, v in sorted(res.items(), key=lambda kv: min(kv[1])):
     med, mn = float(np.median(v)), min(v)
     print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f}")
+# the plain genotype distribution (no masks) on the same table: short-row kernel on / off
+dist_buf = torch.empty(m * 16, dtype=torch.uint8, device="cuda")
+for mode in (1, 0):
+    t.set_option(capi.OPT_SHORT_ROWS, mode)
+    t.scan_distribution_device(0, m, dist_buf.data_ptr(), None)
+    best = 1e9
+    for _ in range(args.reps):
+        t.timer_start(None)
+        t.scan_distribution_device(0, m, dist_buf.data_ptr(), None)
+        best = min(best, t.timer_stop(None))
+    print(f"distribution scan, short-row kernel {'on ' if mode else 'off'}: {best:7.3f} ms  {alg/best/1e6:8.0f} GB/s  {alg/best/1e6/80:5.1f} %")
 t.close()
