@@ -429,11 +429,12 @@ def test_allocation_failure_is_reported_not_fatal():
 
 
 @pytest.mark.parametrize("n,m", [(70, 9), (1000, 777), (8191, 130), (8193, 131), (16400, 257), (24576, 66), (24700, 67),
-                                 (32767, 50), (32768, 50)])
+                                 (32767, 50), (32768, 50), (40000, 33), (57345, 21), (65535, 20), (65536, 20)])
 def test_short_row_kernel(oracle, n, m):
-    """Rows of at most 256 units (N <= 32 767) go through k_scan_cc_short by default -- several rows per
-    wave at a time, masks in registers, packed reductions: same counts and statistics as the oracle and
-    as the row-at-a-time kernel, for every step count (1..4), ragged row counts and sub-ranges."""
+    """Rows of at most 256 units (N <= 32 767) go through k_scan_cc_sub by default -- 16 or 32 lanes per
+    row, double-buffered batches, masks in registers, packed reductions: same counts and statistics as the
+    oracle and as the row-at-a-time kernel, for every lane-group size and step count, ragged row counts
+    and sub-ranges."""
     rng = np.random.default_rng(n * 7 + m)
     codes = _random_codes(rng, m, n, p_missing=0.03)
     cs, ct, nc, nt = _random_masks(oracle, rng, n)
