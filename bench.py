@@ -36,6 +36,8 @@ WORKLOADS = {
     "c1": (10_000, 50_000, "c1: 10k samples x 50k SNPs case/control chi2 scan (plumbing size)"),
     "c2": (100_000, 500_000, "c2: 100k samples x 500k SNPs, per-SNP 3x3 contingency + chi2"),
     "c3": (500_000, 1_000_000, "c3: 500k samples x 1M SNPs, MAF + HWE + case/control chi2 combined scan"),
+    # not a BASELINE.json config: the size of a typical cohort (short rows -> the sub-wave-per-row kernel)
+    "n10k": (10_000, 1_000_000, "10k samples x 1M SNPs, MAF + HWE + case/control chi2 combined scan (short rows)"),
     # configs[4]: all SNP pairs; BASELINE.json gives no sample count for it -> 10 k (5 k / 5 k), stated
     "c5": (10_000, 100_000, "c5: pairwise SNPxSNP epistasis, BOOST KSA pre-screen over 100k SNPs (10k samples)"),
 }
@@ -460,7 +462,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and args.workload == "c3" and not args.snps and not args.no_extra:
-            out["extra_workloads"] = {"c2": side_workload("c2", args.steps, args.warmup)}
+            out["extra_workloads"] = {"c2": side_workload("c2", args.steps, args.warmup),
+                                      "n10k": side_workload("n10k", args.steps, args.warmup)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
