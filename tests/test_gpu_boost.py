@@ -210,3 +210,41 @@ def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_ma
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 0)
         hits0, n0, *_ = t.boost_screen(0, m, 0, m, threshold=30.0, extremes=False)
         assert n0 == int((finite > 30.0).sum())
+
+
+@pytest.mark.parametrize("p_missing", [0.0, 0.02])
+def test_boost_blocks_of_any_geometry_agree_across_kernels(oracle, p_missing):
+    """Rectangles of the pair space that start and end anywhere (not on the 32/64/128-SNP tile grids of
+    the kernels), on a table several tiles wide: every kernel family (vector ALU, one-group-at-a-time
+    MFMA, both-groups MFMA) must return the measures of the full matrix, and the screen its hits."""
+    n, m = 2500, 203
+    rng = np.random.default_rng(11 + int(p_missing * 100))
+    ts = oracle.pack_codes(_codes(rng, m, n, p_missing), "stream")
+    cs, ct, nc, nt = _masks(oracle, rng, n)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, 0)
+        full = t.boost_measures(0, m, 0, m)  # vector-ALU kernel (checked against the oracle above)
+        finite = full[np.isfinite(full)]
+        thr = float(np.quantile(finite, 0.97))
+        rects = [(0, m, 0, m), (0, 1, 0, m), (m - 1, 1, 0, m), (5, 70, 3, 190), (63, 66, 64, 65), (64, 64, 128, 75),
+                 (127, 3, 0, m), (1, 130, 131, 72), (190, 13, 100, 103)]
+        for _ in range(6):
+            a0 = int(rng.integers(0, m)); na = int(rng.integers(1, m - a0 + 1))
+            b0 = int(rng.integers(0, m)); nb = int(rng.integers(1, m - b0 + 1))
+            rects.append((a0, na, b0, nb))
+        for mode in (1, 2, 0):
+            t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mode)
+            for (a0, na, b0, nb) in rects:
+                blk = t.boost_measures(a0, na, b0, nb)
+                want = full[a0:a0 + na, b0:b0 + nb].copy()
+                want[np.arange(a0, a0 + na)[:, None] >= np.arange(b0, b0 + nb)[None, :]] = np.nan
+                assert np.array_equal(np.isnan(blk), np.isnan(want)), (mode, a0, na, b0, nb)
+                ok = ~np.isnan(want)
+                assert np.array_equal(blk[ok], want[ok]), (mode, a0, na, b0, nb)
+                hits, n_hits, n_pairs, _, _ = t.boost_screen(a0, na, b0, nb, threshold=thr, extremes=False)
+                assert n_pairs == int(ok.sum())
+                assert n_hits == int((want[ok] > thr).sum()) == len(hits)
+                for h in hits:
+                    assert h["measure"] == full[h["snp_a"], h["snp_b"]]
