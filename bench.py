@@ -227,7 +227,7 @@ def bench_pairs(args, rank, world, local_rank, dist):
                          "unit": "TOP/s (int8, 2 ops per multiply-add; wall time of the whole screen incl. the "
                                  "per-pair bound / measure epilogue and host round trips)",
                          "frac": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
-                         "kernel": "gw::k_boost_mfma<true>",
+                         "kernel": "gw::k_boost_mfma_seq<true, 2, 2>",
                          "note": "algorithmic MACs only (sample padding to 1024 per group not counted)"},
             "cpu_baseline": None,
         }
