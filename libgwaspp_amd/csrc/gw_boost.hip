@@ -8,14 +8,17 @@
 //   k_margins     computeMargins -> computeMarginalInformation,
 //                 algorithms/epistasis_func.cpp:706-721,
 //                 genotype/common_genotype_func.cpp:173-219
+//   k_retile_cc   the block-tiled copy of the compacted rows the MFMA kernels read
 //   k_boost       the O(M^2) loop of computeBoost (:393-486): margin-assisted
 //                 case/control 3x3 tables (table5.cpp:989-1150) + the
-//                 interaction measure (:424-470) + the threshold list (:482)
+//                 interaction measure (:424-470) + the threshold list (:482),
+//                 vector-ALU form (AND + v_bcnt); launch_boost picks the form
 //
-// Unlike the per-SNP scan this path is ALU-bound (rows are re-used M times
-// from LDS): 9 (or 4) AND+popcount per 32 samples per pair, then ~20 FP64
-// logarithms per pair.  Still no MFMA: AND-popcount has no matrix-core form
-// on CDNA4 short of expanding every bit to a 4-bit element.
+// Unlike the per-SNP scan this path re-uses every row M times: it is compute-
+// bound, and the pair tables are a binary GEMM.  The default forms run on the
+// matrix cores: gw_boost_seq4.hip / gw_boost_seq9.hip (k_boost_mfma_seq, one group
+// at a time) and gw_boost_mfma.hip (both groups at once, any group size); shared
+// device code (measure, bound, operand expansion) in gw_boost_dev.h.
 #include "gw_boost_dev.h"
 
 namespace gw {

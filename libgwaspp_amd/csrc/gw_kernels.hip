@@ -11,16 +11,17 @@
 //   k_scan_cc_compl  SNP loop of inline_cc_maf, algorithms/maf_func.cpp:292-316,
 //                    + MinorAlleleFrequency, algorithms/maf_func.h:46-54, + the
 //                    build-defined HWE / chi-square statistics.
-//                    Three forms of the same scan: row-at-a-time; continuous
+//   k_scan_cc_sub    Four forms of the same scan: row-at-a-time; continuous
 //                    stream (inline-asm loads, counted waits; the c3 default);
-//                    single mask for complementary phenotypes (N up to 1.3 M).
-//   k_scan_dist      getGenotypeDistribution, table5.cpp:577-607
+//                    single mask for complementary phenotypes (N up to 1.3 M);
+//                    a sub-wave of 16 / 32 lanes per row for short rows (N <= 32 k).
+//   k_scan_dist(_sub) getGenotypeDistribution, table5.cpp:577-607
 //   k_pair           getContingencyTable / getCaseControlContingencyTable for a
 //                    list of SNP pairs, table5.cpp:749-800 / 806-895
 //   k_restride_*     the row packings of table5.cpp:277-365 / table3.cpp:260-325
 //   k_simulate*      data/simulate_data.cpp:150-235
 //   k_stream_probe   the scan's traversal with the arithmetic removed
-// (the all-pairs BOOST path is in gw_boost.hip)
+// (the all-pairs BOOST path is in gw_boost*.hip)
 #include "gw_kernels.h"
 
 namespace gw {
