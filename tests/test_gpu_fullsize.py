@@ -16,10 +16,13 @@ CONFIGS = {
     "c1": (10_000, 50_000),        # BASELINE.json configs[0]
     "c2": (100_000, 500_000),      # configs[1], 12.5 GB
     "c3": (500_000, 1_000_000),    # configs[2], 125 GB
+    # not BASELINE configs: typical cohort sizes, through the sub-wave kernels (16 and 32 lanes per row)
+    "n6k": (6_000, 1_000_000),
+    "n20k": (20_000, 1_000_000),
 }
 
 
-@pytest.mark.parametrize("cfg", ["c1", "c2", "c3"])
+@pytest.mark.parametrize("cfg", ["c1", "c2", "c3", "n6k", "n20k"])
 def test_full_size_properties(oracle, cfg):
     if gw.device_count() == 0:
         pytest.fail("no HIP device visible")
