@@ -19,6 +19,7 @@
 #pragma once
 #include <string>
 #include <utility>
+#include <future>
 #include <vector>
 
 #include "genetics/genotype/geno_table.h"
@@ -81,7 +82,9 @@ public:
     // pass: pairs (i, j, measure) with measure > threshold, in the reference's (i, j) visiting order
     void boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing);
     void setScanWindow(uint rows) { window = rows ? rows : 1; invalidate(); }
-    gw_table *handle() { return tbl; }
+    // scan window k+1 on a worker thread while the caller walks window k (on by default)
+    void setPrefetch(bool on) { drop_prefetch(); prefetch = on; }
+    gw_table *handle() { settle(); return tbl; }
 
 protected:
     void initialize();
@@ -89,6 +92,12 @@ protected:
     void install(CaseControlSet &ccs);
     void fill_dist_cache(uint rIdx);
     void fill_cc_cache(uint rIdx);
+    // the window after the one just served, scanned ahead by a worker thread.  The C-ABI is one-thread-per-
+    // table: every method that enters it calls settle() first (the worker is then the only caller)
+    void start_prefetch(int kind, ulong begin);
+    bool take_prefetch(int kind, ulong begin);   // true: the caches now hold that window
+    void settle();                               // wait for the worker; its result stays usable
+    void drop_prefetch();                        // wait and discard (data or masks changed)
     void pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABLE_T &ct);
 
     gw_table *tbl;
@@ -100,6 +109,16 @@ protected:
     std::vector<uint> dist_cache, cc_cache;
     std::vector<double> stat_cache;
     ulong dist_begin, dist_count, cc_begin, cc_count;
+    bool prefetch;
+    struct Ahead {
+        std::future<int> done;
+        bool valid;
+        int kind;  // 0 distribution, 1 case/control
+        ulong begin, count;
+        std::vector<uint> counts;
+        std::vector<double> stats;
+        Ahead() : valid(false), kind(0), begin(0), count(0) {}
+    } ahead;
 
     // installed masks
     const CaseControlSet *installed;

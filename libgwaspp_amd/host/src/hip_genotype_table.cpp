@@ -37,7 +37,7 @@ inline void to_freq(const uint *c, frequency_table &ft) {
 
 HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
     : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
-      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), installed(nullptr),
+      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), prefetch(true), installed(nullptr),
       installed_rev(0), row_cached(-1) {
     initialize();
 }
@@ -62,16 +62,65 @@ void HipGenotypeTable::initialize() {
               << " individuals resident in HBM" << std::endl;
 }
 
-HipGenotypeTable::~HipGenotypeTable() { gw_table_destroy(tbl); }
+HipGenotypeTable::~HipGenotypeTable() {
+    drop_prefetch();
+    gw_table_destroy(tbl);
+}
 
 void HipGenotypeTable::invalidate() {
+    drop_prefetch();
     dist_count = cc_count = 0;
     row_cached = -1;
+}
+
+void HipGenotypeTable::settle() {
+    if (ahead.valid && ahead.done.valid()) ahead.done.wait();
+}
+
+void HipGenotypeTable::drop_prefetch() {
+    if (ahead.valid && ahead.done.valid()) ahead.done.wait();
+    ahead.valid = false;
+}
+
+void HipGenotypeTable::start_prefetch(int kind, ulong begin) {
+    if (!prefetch || begin >= (ulong)max_row) return;
+    drop_prefetch();
+    ahead.kind = kind;
+    ahead.begin = begin;
+    ahead.count = std::min<ulong>(window, (ulong)max_row - begin);
+    ahead.counts.resize(ahead.count * (kind ? GW_N_COUNTS : 4));
+    if (kind) ahead.stats.resize(ahead.count * GW_N_STATS);
+    gw_table *h = tbl;
+    Ahead *a = &ahead;
+    ahead.done = std::async(std::launch::async, [h, a]() -> int {
+        return a->kind ? gw_scan_case_control(h, a->begin, a->count, a->counts.data(), a->stats.data())
+                       : gw_scan_distribution(h, a->begin, a->count, a->counts.data());
+    });
+    ahead.valid = true;
+}
+
+bool HipGenotypeTable::take_prefetch(int kind, ulong begin) {
+    if (!ahead.valid || ahead.kind != kind || ahead.begin != begin) return false;
+    const int rc = ahead.done.get();
+    ahead.valid = false;
+    if (rc != GW_OK) return false;  // the caller scans again on its own thread and reports the error
+    if (kind) {
+        cc_cache.swap(ahead.counts);
+        stat_cache.swap(ahead.stats);
+        cc_begin = begin;
+        cc_count = ahead.count;
+    } else {
+        dist_cache.swap(ahead.counts);
+        dist_begin = begin;
+        dist_count = ahead.count;
+    }
+    return true;
 }
 
 // --------------------------------------------------------------------- ingest
 
 void HipGenotypeTable::addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim) {
+    drop_prefetch();  // the C-ABI is entered by one thread at a time; the data change
     die_unless_ok(gw_table_add_genotype_row(tbl, (uint64_t)rIdx, p_begin, p_end, delim), "addGenotypeRow");
     invalidate();
 }
@@ -86,6 +135,7 @@ void HipGenotypeTable::addGenotypeRow(int rIdx, std::string::const_iterator &it,
 
 void HipGenotypeTable::addGenotypeRows(int rBegin, const std::vector<std::pair<const char *, const char *> > &rows,
                                        char delim) {
+    drop_prefetch();
     std::vector<const char *> b(rows.size()), e(rows.size());
     for (size_t k = 0; k < rows.size(); ++k) { b[k] = rows[k].first; e[k] = rows[k].second; }
     die_unless_ok(gw_table_add_genotype_rows(tbl, (uint64_t)rBegin, rows.size(), b.data(), e.data(), delim, 0),
@@ -94,6 +144,7 @@ void HipGenotypeTable::addGenotypeRows(int rBegin, const std::vector<std::pair<c
 }
 
 void HipGenotypeTable::addGenotype(int rIdx, int cIdx, const std::string &gt) {
+    drop_prefetch();
     // read-modify-write of one row in the reference's stream packing
     gw_geometry g;
     die_unless_ok(gw_table_geometry(tbl, &g), "gw_table_geometry");
@@ -126,6 +177,7 @@ const char *HipGenotypeTable::decodeGenotype(ushort enc) { return gt_text[enc < 
 bool HipGenotypeTable::isGenotypeHomozygous(ushort enc) { return enc < 16 && (enc >> 2) == (enc & 3); }
 
 DataBlock HipGenotypeTable::operator()(int r, int c) {
+    settle();
     gw_geometry g;
     die_unless_ok(gw_table_geometry(tbl, &g), "gw_table_geometry");
     if (row_cached != r) {
@@ -152,10 +204,14 @@ void HipGenotypeTable::getContingencyTable(uint, uint, ushort *, ContingencyTabl
 void HipGenotypeTable::fill_dist_cache(uint rIdx) {
     const ulong begin = (rIdx / window) * (ulong)window;
     const ulong n = std::min<ulong>(window, (ulong)max_row - begin);
-    dist_cache.resize(n * 4);
-    die_unless_ok(gw_scan_distribution(tbl, begin, n, dist_cache.data()), "gw_scan_distribution");
-    dist_begin = begin;
-    dist_count = n;
+    if (!take_prefetch(0, begin)) {
+        drop_prefetch();
+        dist_cache.resize(n * 4);
+        die_unless_ok(gw_scan_distribution(tbl, begin, n, dist_cache.data()), "gw_scan_distribution");
+        dist_begin = begin;
+        dist_count = n;
+    }
+    start_prefetch(0, begin + n);  // the callers walk r = 0 .. M-1 in order (maf_func.cpp:271-290, 318-335)
 }
 
 void HipGenotypeTable::getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist) {
@@ -169,6 +225,7 @@ void HipGenotypeTable::getGenotypeDistribution(uint rIdx, GenotypeDistribution &
 
 void HipGenotypeTable::install(CaseControlSet &ccs) {
     if (installed == &ccs && installed_rev == ccs.revision()) return;
+    drop_prefetch();
     die_unless_ok(gw_table_set_case_control(tbl, ccs.stream_case_begin(), ccs.stream_control_begin(),
                                             ccs.stream_block_count(), ccs.getCaseCount(), ccs.getControlCount()),
                   "gw_table_set_case_control");
@@ -194,11 +251,15 @@ void HipGenotypeTable::fill_cc_cache(uint rIdx) {
     }
     const ulong begin = (rIdx / window) * (ulong)window;
     const ulong n = std::min<ulong>(window, (ulong)max_row - begin);
-    cc_cache.resize(n * GW_N_COUNTS);
-    stat_cache.resize(n * GW_N_STATS);
-    die_unless_ok(gw_scan_case_control(tbl, begin, n, cc_cache.data(), stat_cache.data()), "gw_scan_case_control");
-    cc_begin = begin;
-    cc_count = n;
+    if (!take_prefetch(1, begin)) {
+        drop_prefetch();
+        cc_cache.resize(n * GW_N_COUNTS);
+        stat_cache.resize(n * GW_N_STATS);
+        die_unless_ok(gw_scan_case_control(tbl, begin, n, cc_cache.data(), stat_cache.data()), "gw_scan_case_control");
+        cc_begin = begin;
+        cc_count = n;
+    }
+    start_prefetch(1, begin + n);  // the callers walk r = 0 .. M-1 in order (maf_func.cpp:304-314)
 }
 
 void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd) {
@@ -231,6 +292,7 @@ const double *HipGenotypeTable::getAssociationStatistics(uint rIdx) {
 // ----------------------------------------------------------------------- pairs
 
 void HipGenotypeTable::getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct) {
+    settle();
     const uint pair[2] = {rIdx1, rIdx2};
     CONTIN_TABLE_T c;
     die_unless_ok(gw_pair_contingency(tbl, pair, 1, c.contin), "gw_pair_contingency");
@@ -240,6 +302,7 @@ void HipGenotypeTable::getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTa
 }
 
 void HipGenotypeTable::pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABLE_T &ct) {
+    settle();
     const uint pair[2] = {r1, r2};
     die_unless_ok(gw_pair_case_control_contingency(tbl, pair, 1, cs.contin, ct.contin),
                   "gw_pair_case_control_contingency");
@@ -287,6 +350,7 @@ void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, co
 
 void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
                                                        std::vector<uint> &cases, std::vector<uint> &ctrls) {
+    settle();
     install(ccs);
     cases.resize(n_pairs * 16);
     ctrls.resize(n_pairs * 16);
@@ -295,6 +359,7 @@ void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t
 }
 
 void HipGenotypeTable::getContingencyTables(const uint *pairs, size_t n_pairs, std::vector<uint> &tables) {
+    settle();
     tables.resize(n_pairs * 16);
     die_unless_ok(gw_pair_contingency(tbl, pairs, n_pairs, tables.data()), "gw_pair_contingency");
 }
@@ -302,6 +367,7 @@ void HipGenotypeTable::getContingencyTables(const uint *pairs, size_t n_pairs, s
 void HipGenotypeTable::getSelectedCaseControlContingencyTables(const uint *pairs, size_t n_pairs,
                                                                std::vector<CONTIN_TABLE_T> &cases,
                                                                std::vector<CONTIN_TABLE_T> &ctrls) {
+    settle();
     if (!installed) std::abort();
     std::vector<uint> cs(n_pairs * 16), ct(n_pairs * 16);
     if (n_pairs)
@@ -321,6 +387,7 @@ void HipGenotypeTable::getSelectedCaseControlContingencyTables(const uint *pairs
 }
 
 void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing) {
+    settle();
     if (!installed) std::abort();
     passing.clear();
     std::vector<gw_boost_hit> hits(1u << 16);

@@ -30,7 +30,7 @@ using namespace libgwaspp::genetics;
 using namespace libgwaspp::algorithms;
 
 static void usage() {
-    std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] "
+    std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] [--scan-window ROWS] [--no-prefetch] "
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
                  "--valid-geno|--contin-debug|--epi-debug|--test-boost-epi|--contin-perform|--assoc\n";
     std::exit(2);
@@ -42,13 +42,16 @@ static void print_table(std::ostream &o, const CONTIN_TABLE_T &t) {
 
 int main(int argc, char **argv) {
     std::string tped, tfam, out_path, mode;
-    int device = 0;
+    int device = 0, scan_window = 0;
+    bool prefetch = true;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if ((a == "-g" || a == "--genotype") && i + 1 < argc) tped = argv[++i];
         else if ((a == "-p" || a == "--phenotype") && i + 1 < argc) tfam = argv[++i];
         else if ((a == "-o" || a == "--output") && i + 1 < argc) out_path = argv[++i];
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "--scan-window" && i + 1 < argc) scan_window = std::atoi(argv[++i]);  // rows per device scan
+        else if (a == "--no-prefetch") prefetch = false;
         else if (a == "-t") {}  // transposed input is the only form here
         else if (a.rfind("--", 0) == 0) mode = a;
         else usage();
@@ -67,6 +70,10 @@ int main(int argc, char **argv) {
         out = &file;
     }
     GenoTable &gt = *gd.getGenotypeTable();
+    if (HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt)) {
+        if (scan_window > 0) hip->setScanWindow((uint)scan_window);
+        hip->setPrefetch(prefetch);
+    }
     const int M = gd.getGenotypedMarkersCount(), N = gd.getGenotypedIndividualsCount();
 
     if (mode == "--test-inline-maf") {

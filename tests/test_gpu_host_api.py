@@ -27,11 +27,11 @@ def _cli():
         subprocess.run(["make", "-C", os.path.join(ROOT, "libgwaspp_amd", "host"), "-s"], check=True)
 
 
-def _run(name, mode, out=None):
+def _run(name, mode, out=None, extra=()):
     cmd = [CLI, "-g", os.path.join(PERL_DIR, name + ".tped"), "-p", os.path.join(PERL_DIR, name + ".tfam")]
     if out:
         cmd += ["-o", out]
-    r = subprocess.run(cmd + [mode], check=True, capture_output=True, text=True)
+    r = subprocess.run(cmd + list(extra) + [mode], check=True, capture_output=True, text=True)
     return r.stdout
 
 
@@ -218,3 +218,23 @@ def test_contingency_performance_harness():
     line = [ln for ln in out.splitlines() if ln.startswith("Contingencies 40:")][0]
     words = (((70 // 16 + 1) + 3) & ~3) // 4
     assert f"(sum of all cells {40 * 39 // 2 * words * 64})" in line
+
+
+@pytest.mark.parametrize("window", [1, 3, 7, 64])
+def test_getters_served_from_prefetched_windows(window, tmp_path):
+    """The per-row getters are served from device scans of `window` rows; the window after the one being
+    walked is scanned ahead on a worker thread.  Walking 40- and 24-row tables through 1 .. 40 windows, with and
+    without the worker, must print what one big window prints."""
+    name_cc = "cc_m24_n1000"
+    name_plain = "plain_m40_n70"
+    ref_plain = _table_lines(_run(name_plain, "--test-inline-maf"))
+    out = str(tmp_path / "ref")
+    _run(name_cc, "--test-inline-cc-maf", out)
+    ref_cc = (_table_lines(open(out + ".case").read()), _table_lines(open(out + ".control").read()))
+    ref_assoc = _run(name_cc, "--assoc")
+    for extra in (["--scan-window", str(window)], ["--scan-window", str(window), "--no-prefetch"]):
+        assert _table_lines(_run(name_plain, "--test-inline-maf", extra=extra)) == ref_plain
+        o = str(tmp_path / ("w%d_%d" % (window, len(extra))))
+        _run(name_cc, "--test-inline-cc-maf", o, extra=extra)
+        assert (_table_lines(open(o + ".case").read()), _table_lines(open(o + ".control").read())) == ref_cc
+        assert _run(name_cc, "--assoc", extra=extra) == ref_assoc
