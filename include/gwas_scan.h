@@ -263,8 +263,9 @@ typedef enum gw_option {
                                 2 diagnostic: gw_boost_measures returns the bound instead of the measure */
     GW_OPT_BOOST_MATRIX_CORES = 9, /* pair tables as int8 MFMA dot products of class vectors (1, default: four
                                 products per pair when no call of the table is missing, nine otherwise)
-                                or AND + popcount on the vector ALU (0); 2 = as 1 but the nine-cell form
-                                always on 16x16 tiles (its fallback for case groups >= 65 536 members) */
+                                or AND + popcount on the vector ALU (0); 2 = as 1 but always the kernels
+                                that keep both groups' accumulators (what case groups >= 65 536 members
+                                get) */
     GW_OPT_SHORT_ROWS = 10,  /* rows of at most 256 units (N <= 32 k) with every other shape option on auto:
                                 1 (default) several rows per wave at a time, masks in registers; 0 the
                                 row-at-a-time kernel; get returns whether the current table uses it */

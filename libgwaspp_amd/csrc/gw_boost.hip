@@ -17,7 +17,8 @@
 // Unlike the per-SNP scan this path re-uses every row M times: it is compute-
 // bound, and the pair tables are a binary GEMM.  The default forms run on the
 // matrix cores: gw_boost_seq4.hip / gw_boost_seq9.hip (k_boost_mfma_seq, one group
-// at a time) and gw_boost_mfma.hip (both groups at once, any group size); shared
+// at a time) and gw_boost_mfma.hip / gw_boost_both9.hip (both groups at once, any
+// group size); shared
 // device code (measure, bound, operand expansion) in gw_boost_dev.h.
 #include "gw_boost_dev.h"
 
@@ -399,7 +400,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct, bool narrow_tiles) {
+                        float bound_threshold, const u32x4 *d_cct, bool both_groups) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -409,10 +410,11 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.marf = d_marf; a.bound_threshold = bound_threshold;
     a.cct = d_cct;
     const bool pre = prefilter && d_marf;
-    const bool small_case_group = wc * 32u < 65536u && !narrow_tiles;  // case counts fit uint16
+    const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
     if (d_cct && d_marf && small_case_group)  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
         return fast ? launch_boost_mfma_seq4(a, pre, stream) : launch_boost_mfma_seq9(a, pre, stream);
-    if (d_cct && (fast || d_marf)) return launch_boost_mfma_both(a, fast, pre, stream);  // any group size
+    if (d_cct && fast) return launch_boost_mfma_both4(a, pre, stream);           // any group size, 2 waves per SIMD
+    if (d_cct && d_marf) return launch_boost_mfma_both9(a, pre, stream);         // any group size, 1 wave per SIMD
     return launch_boost_valu(a, fast, pre, stream);
 }
 

@@ -1,0 +1,16 @@
+// gw_boost_both9.hip -- k_boost_mfma_seq<PRE, 3, 1, BOTH> (see gw_boost_seq.inc): nine cells, case groups of any
+// size: both groups' accumulator tiles (288 registers) stay in the register file, one wave per SIMD
+#include "gw_boost_dev.h"
+
+namespace gw {
+
+#include "gw_boost_seq.inc"
+
+hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream) {
+    const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+    if (pre) hipLaunchKernelGGL((k_boost_mfma_seq<true, 3, 1, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_boost_mfma_seq<false, 3, 1, true>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace gw

@@ -1,5 +1,5 @@
 // gw_boost_dev.h -- device-side pieces shared by the pair-path translation units
-// (gw_boost.hip, gw_boost_mfma.hip, gw_boost_seq4.hip, gw_boost_seq9.hip; split so that they compile in
+// (gw_boost.hip, gw_boost_mfma.hip, gw_boost_seq4.hip, gw_boost_seq9.hip, gw_boost_both9.hip; split so that they compile in
 // parallel: the unrolled per-pair epilogues make each of them a minute of compile time).
 #pragma once
 #include <type_traits>
@@ -132,8 +132,9 @@ __device__ __forceinline__ i32x4 expand_b(uint32_t w, uint32_t rb, int hk) {
 
 // ---- per-file launchers behind launch_boost (grid and <PRE> chosen inside)
 hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);        // gw_boost.hip
-hipError_t launch_boost_mfma_both(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);   // gw_boost_mfma.hip
+hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_mfma.hip
 hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq4.hip
 hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
+hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
 
 }  // namespace gw

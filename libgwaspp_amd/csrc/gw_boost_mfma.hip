@@ -1,4 +1,5 @@
-// gw_boost_mfma.hip -- the both-groups-at-once int8 MFMA pair kernels (see gw_boost.hip for the path)
+// gw_boost_mfma.hip -- the both-groups-at-once int8 MFMA pair kernel for the four corners (case groups of
+// any size; see gw_boost.hip for the path)
 #include "gw_boost_dev.h"
 
 namespace gw {
@@ -240,211 +241,10 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// The same on tables WITH missing calls: all nine cells of both 3 x 3 tables are
-// counted (table5.cpp:989-1064), nine products per pair and group.  Nine 32 x 32
-// accumulator tiles per group would be 288 registers, so this form uses
-// v_mfma_i32_16x16x64_i8 (4 registers per product): one wave = 16 A rows x 32 B
-// rows (two 16-row B tiles) = 2 x 9 x 2 x 4 = 144 accumulators; workgroup =
-// 2 x 2 waves = 32 x 64 pairs.  Lane (r, q) = row r of the tile, k-group q: it
-// owns samples 32q .. 32q+31 of the chunk (one word per plane), two steps of 16.
-// Operand expansion as in k_boost_mfma (expand_a / expand_b, products of 64).
-// ---------------------------------------------------------------------------
-namespace {
-constexpr int M9A = 32, M9B = 64;  // workgroup tile: A rows x B rows
-typedef int i32x4v __attribute__((ext_vector_type(4)));
-}  // namespace
-
-template <bool PRE>
-__global__ void __launch_bounds__(256, 2) k_boost_mfma9(BoostArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_marf[(M9A + M9B) * 24];  // SnpMarginF of the tile's rows
-
-    const uint32_t a0 = a.a_begin + blockIdx.y * M9A, b0 = a.b_begin + blockIdx.x * M9B;
-    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
-    if (a0 + 1u >= min(b0 + (uint32_t)M9B, b_end)) return;  // nothing above the diagonal in this tile
-
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t wy = wave >> 1, wx = wave & 1u;
-    const uint32_t fr = lane & 15u, fq = lane >> 4;
-
-    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;
-    auto unit = [&](uint32_t snp) {  // this lane's 16-byte unit of chunk 0: half fq >> 1 of the row
-        return a.cct + ((uint64_t)(snp >> 6) * nchunk * 64u + (snp & 63u)) * 2u + (fq >> 1);
-    };
-    const u32x4 *ga = unit(min(a0 + wy * 16u + fr, a_end - 1u));
-    const u32x4 *gb0 = unit(min(b0 + wx * 32u + fr, b_end - 1u));
-    const u32x4 *gb1 = unit(min(b0 + wx * 32u + 16u + fr, b_end - 1u));
-    const uint32_t ws = fq & 1u;  // which word of the half
-
-    i32x4v acc[2][2][9];  // [group][B tile][3 * class of A + class of B]
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) acc[g][tb][c] = i32x4v{0, 0, 0, 0};
-
-    constexpr int RING = 4;
-    uint2 ua[RING], ub0[RING], ub1[RING];  // {plane 0 word, plane 1 word} of the lane's 32 samples
-    auto fetch = [&](uint32_t c, uint2 &xa, uint2 &xb0, uint2 &xb1) {
-        const u32x4 va = ga[(uint64_t)c * 128u], vb0 = gb0[(uint64_t)c * 128u], vb1 = gb1[(uint64_t)c * 128u];
-        xa = ws ? make_uint2(va[1], va[3]) : make_uint2(va[0], va[2]);
-        xb0 = ws ? make_uint2(vb0[1], vb0[3]) : make_uint2(vb0[0], vb0[2]);
-        xb1 = ws ? make_uint2(vb1[1], vb1[3]) : make_uint2(vb1[0], vb1[2]);
-    };
-#pragma unroll
-    for (int k = 0; k < RING; ++k) fetch(k, ua[k], ub0[k], ub1[k]);
-    const uint32_t last_chunk = nchunk - 1u;
-
-    auto chunk = [&](const uint2 &pa, const uint2 &pb0, const uint2 &pb1, i32x4v (&d)[2][9]) {
-        // class words: aa = code 1, ab = code 2, bb = code 3 (plane0 = codes 1,3; plane1 = codes 2,3)
-        const uint32_t ca3[3] = {pa.x & ~pa.y, pa.y & ~pa.x, pa.x & pa.y};
-        uint32_t cb3[2][3], rb3[2][3];
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const uint2 &pb = tb ? pb1 : pb0;
-            cb3[tb][0] = pb.x & ~pb.y; cb3[tb][1] = pb.y & ~pb.x; cb3[tb][2] = pb.x & pb.y;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rb3[tb][c] = __builtin_bswap32(__builtin_bitreverse32(cb3[tb][c])) >> 1;
-        }
-#pragma unroll
-        for (int hk = 0; hk < 2; ++hk) {
-            i32x4 xa[3], yb[2][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                xa[c] = expand_a(ca3[c], hk);
-                yb[0][c] = expand_b(cb3[0][c], rb3[0][c], hk);
-                yb[1][c] = expand_b(cb3[1][c], rb3[1][c], hk);
-            }
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int x = 0; x < 3; ++x)
-#pragma unroll
-                    for (int y = 0; y < 3; ++y)
-                        d[tb][3 * x + y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xa[x], yb[tb][y], d[tb][3 * x + y], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 18; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (16 cycles)
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // 3 VALU
-            }
-        }
-    };
-    auto round = [&](uint32_t c0, i32x4v (&d)[2][9]) {
-        static_for<0, RING>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            chunk(ua[k], ub0[k], ub1[k], d);
-            fetch(min(c0 + k + RING, last_chunk), ua[k], ub0[k], ub1[k]);  // past the end: re-read, unused
-        });
-    };
-    for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0, acc[0]);
-    for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0, acc[1]);
-
-    // ---- per pair.  C layout of the 16x16 MFMA: column (B index) = lane & 15, row (A index) = 4 (lane >> 4) + reg
-    if (PRE) {
-        for (uint32_t idx = t; idx < (uint32_t)(M9A + M9B) * 24u; idx += 256u) {
-            const uint32_t row = idx / 24u, k = idx % 24u;
-            const uint32_t snp = row < (uint32_t)M9A ? min(a0 + row, a_end - 1u) : min(b0 + (row - M9A), b_end - 1u);
-            s_marf[idx] = reinterpret_cast<const uint32_t *>(a.marf + snp)[k];
-        }
-        __syncthreads();
-    }
-    const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
-    const uint32_t i_base = a0 + wy * 16u + 4u * fq;
-    auto load_marf = [&](uint32_t row) {
-        SnpMarginF m;
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-            *reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(&m) + 4 * q) =
-                *reinterpret_cast<const u32x4 *>(s_marf + row * 24u + 4 * q);
-        return m;
-    };
-
-    uint32_t need = 0;  // bit 4 tb + reg: that pair still wants its FP64 measure
-    unsigned long long n_eval = 0;
-    static_for<0, 8>([&](auto pc) {
-        constexpr int tb = decltype(pc)::value >> 2, r = decltype(pc)::value & 3;
-        const uint32_t i = i_base + r, j = b0 + wx * 32u + tb * 16u + fr;
-        if (i < a_end && j < b_end && i < j) {
-            ++n_eval;
-            if (PRE) {
-                uint32_t ca[9], co[9];
-#pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    ca[c] = (uint32_t)acc[0][tb][c][r] >> 6;  // every product was 64
-                    co[c] = (uint32_t)acc[1][tb][c][r] >> 6;
-                }
-                const float bound = boost_bound(ca, co, load_marf(i - a0), load_marf(M9A + (j - b0)), nf, inv_n);
-                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
-                else if (!(bound < a.bound_threshold)) need |= 1u << (4 * tb + r);
-            } else {
-                need |= 1u << (4 * tb + r);
-            }
-        }
-    });
-
-    double vmax = -1.0e300, vmin = 1.0e300;
-    while (need) {
-        const int p = __ffs((int)need) - 1;
-        need &= need - 1u;
-        uint32_t ca[9], co[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            uint32_t x = 0, y = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                x = p == q ? (uint32_t)acc[0][q >> 2][c][q & 3] : x;
-                y = p == q ? (uint32_t)acc[1][q >> 2][c][q & 3] : y;
-            }
-            ca[c] = x >> 6;
-            co[c] = y >> 6;
-        }
-        const uint32_t i = i_base + (p & 3), j = b0 + wx * 32u + (p >> 2) * 16u + fr;
-        const SnpMargin m1 = a.mar[i], m2 = a.mar[j];
-        const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
-        if (!PRE) {
-            vmax = fmax(vmax, measure);
-            vmin = fmin(vmin, measure);
-        }
-        if (measure > a.threshold) {  // :482-484
-            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
-            if (slot < a.max_hits) {
-                BoostHit h;
-                h.snp_a = i;
-                h.snp_b = j;
-                h.measure = measure;
-                a.hits[slot] = h;
-            }
-        }
-        if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_eval += __shfl_xor(n_eval, off, 64);
-        if (!PRE) {
-            vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
-            vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
-        }
-    }
-    if (lane == 0 && n_eval) {
-        atomicAdd(&a.tally[1], n_eval);
-        if (!PRE) {
-            atomicMax(&a.tally[2], ordered(vmax));
-            atomicMin(&a.tally[3], ordered(vmin));
-        }
-    }
-}
-
-hipError_t launch_boost_mfma_both(const BoostArgs &a, bool fast, bool pre, hipStream_t stream) {
-    if (fast) {
-        const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
-        if (pre) hipLaunchKernelGGL(k_boost_mfma<true>, grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(k_boost_mfma<false>, grid, dim3(256), 0, stream, a);
-    } else {
-        const dim3 grid((a.n_b + M9B - 1) / M9B, (a.n_a + M9A - 1) / M9A);
-        if (pre) hipLaunchKernelGGL(k_boost_mfma9<true>, grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(k_boost_mfma9<false>, grid, dim3(256), 0, stream, a);
-    }
+hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t stream) {
+    const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+    if (pre) hipLaunchKernelGGL(k_boost_mfma<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_boost_mfma<false>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

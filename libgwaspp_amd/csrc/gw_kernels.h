@@ -125,8 +125,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         // tables without a missing call: corners as int8 MFMA dot products (k_boost_mfma)
                         // over the block-tiled copy of the compacted rows (launch_retile_cc), or null
                         const u32x4 *d_cct = nullptr,
-                        // nine-cell tables: force the 16x16-tile kernel (otherwise only for case groups >= 65 536)
-                        bool narrow_tiles = false);
+                        // force the kernels that keep both groups' accumulators (what case groups >= 65 536 get)
+                        bool both_groups = false);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

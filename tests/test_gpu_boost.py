@@ -82,7 +82,7 @@ def test_boost_measures_vs_oracle(oracle, n, m, p_missing):
         # the int8-MFMA kernels (4 products per pair without missing calls, 9 with) are the default: the
         # vector-ALU kernel must give the same counts, hence bit-identical measures
         assert t.get_option(gw.capi.OPT_BOOST_MATRIX_CORES) == 1
-        for mode in (0, 2):  # 0: vector ALU; 2: nine-cell tables on 16x16 MFMA tiles (the large-group fallback)
+        for mode in (0, 2):  # 0: vector ALU; 2: the both-groups MFMA kernels (what large case groups get)
             t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mode)
             again = t.boost_measures(0, m, 0, m)
             ok_all = ~np.isnan(got)

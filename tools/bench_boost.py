@@ -20,6 +20,7 @@ ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--missing-q16", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--valu", action="store_true", help="AND + popcount kernel instead of the int8 MFMA one")
+ap.add_argument("--mode", type=int, default=1, help="GW_OPT_BOOST_MATRIX_CORES: 1 default, 2 both-groups kernels")
 args = ap.parse_args()
 
 m, n = args.snps, args.samples
@@ -28,6 +29,8 @@ t.simulate(0x5EED, 0, args.missing_q16)
 t.simulate_phenotype(0x5EED)
 if args.valu:
     t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, 0)
+elif args.mode != 1:
+    t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, args.mode)
 t0 = time.perf_counter()
 t.boost_screen(0, min(m, 64), 0, min(m, 64))  # builds the compacted rows + margins
 prep = time.perf_counter() - t0
