@@ -233,7 +233,7 @@ def bench_pairs(args, rank, world, local_rank, dist):
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
-            k = 300
+            k = 1200  # ~7 x 10^5 pairs, a few seconds of one host core
             rows = table.download_rows(0, k)
             cs, ct, nc, nt = table.get_case_control()
             t1 = time.perf_counter()
