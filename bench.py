@@ -423,8 +423,10 @@ def main():
                  "blocks_per_cu": table.get_option(capi.OPT_BLOCKS_PER_CU),
                  "nontemporal": table.get_option(capi.OPT_NONTEMPORAL),
                  "continuous_stream": table.get_option(capi.OPT_PIPELINE),
-                 "single_mask": table.get_option(capi.OPT_COMPLEMENT)}
-        kernel_name = ("gw::k_scan_cc_compl" if shape["single_mask"] else
+                 "single_mask": table.get_option(capi.OPT_COMPLEMENT),
+                 "sub_wave_rows": table.get_option(capi.OPT_SHORT_ROWS)}
+        kernel_name = ("gw::k_scan_cc_sub" if shape["sub_wave_rows"] else
+                       "gw::k_scan_cc_compl" if shape["single_mask"] else
                        "gw::k_scan_cc_pipe" if shape["continuous_stream"] else "gw::k_scan_cc")
         out = {
             "metric": "SNPs/sec case/control chi2 scan",
