@@ -269,6 +269,12 @@ typedef enum gw_option {
     GW_OPT_SHORT_ROWS = 10,  /* rows of at most 256 units (N <= 32 k) with every other shape option on auto:
                                 1 (default) several rows per wave at a time, masks in registers; 0 the
                                 row-at-a-time kernel; get returns whether the current table uses it */
+    GW_OPT_COLUMN_SEGMENT = 11, /* column-segmented scan: the samples are walked in segments whose two masks fit
+                                the LDS, six partial sums per SNP accumulate in a scratch array and a last
+                                kernel finishes the rows.  0 (default) auto = only where one pass would read
+                                the masks through L2 (N > ~650 k with arbitrary masks, > ~1.3 M with
+                                complementary ones), segments of 4096 units (524 288 samples); -1 never;
+                                > 0 that many 16-byte units per segment; get returns the segment in use */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

@@ -27,6 +27,7 @@ OPT_UNROLL, OPT_MASK_IN_LDS, OPT_BLOCKS_PER_CU, OPT_NONTEMPORAL, OPT_BLOCK_THREA
 OPT_BOOST_PREFILTER = 8
 OPT_BOOST_MATRIX_CORES = 9
 OPT_SHORT_ROWS = 10
+OPT_COLUMN_SEGMENT = 11
 
 
 class GwError(RuntimeError):

@@ -89,7 +89,9 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0;
+    uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
+    size_t raw_bytes = 0;
 };
 
 namespace {
@@ -101,7 +103,10 @@ int use_device(gw_table *t) {
 
 hipStream_t pick_stream(gw_table *t, void *s) { return s ? (hipStream_t)s : t->stream; }
 
-gw::ScanShape scan_shape(const gw_table *t) {
+// `seg_units` > 0: the shape for one column segment of that many units (row-at-a-time or continuous-stream
+// kernel with both masks in LDS; no single-mask or sub-wave form)
+gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
+    const uint32_t units = seg_units ? seg_units : t->tv.units;
     // Defaults from the round-1 sweeps on MI355X (profiles/r01_sweep_*.txt):
     //   masks fill more than half the LDS (N > ~320 k): one 256-thread workgroup per CU (one wave per
     //     SIMD) running the continuous-stream kernel with two 2-unit buffers per lane and plane --
@@ -114,11 +119,11 @@ gw::ScanShape scan_shape(const gw_table *t) {
     sh.nontemporal = t->opt_nt;
     const bool want_lds = (t->opt_mask_lds < 0) ? true : (t->opt_mask_lds != 0);
     // single-mask kernel when the control mask is the complement of the case mask
-    const size_t one_mask = (size_t)t->tv.units * sizeof(gw::u32x4);
+    const size_t one_mask = (size_t)units * sizeof(gw::u32x4);
     // (auto: only where two masks do not fit the LDS -- 650 k < N <= 1.3 M, 86 % vs 75 % of the HBM
     // peak measured at N = 1 M; where both fit the two kernels run at the same speed)
     const bool compl_wanted = t->opt_complement == 2 || (t->opt_complement == 1 && 2 * one_mask > t->lds_cap);
-    const bool compl_ok = compl_wanted && t->masks_complementary && want_lds && t->opt_nt && t->opt_pipeline != 1 &&
+    const bool compl_ok = !seg_units && compl_wanted && t->masks_complementary && want_lds && t->opt_nt && t->opt_pipeline != 1 &&
                           one_mask <= t->lds_cap;
     const size_t raw_need = compl_ok ? one_mask : 2 * one_mask;
     bool lds = want_lds && raw_need <= t->lds_cap;
@@ -132,13 +137,13 @@ gw::ScanShape scan_shape(const gw_table *t) {
     if (sh.pipeline) {
         if (unroll > 4) unroll = 4;
         const uint32_t step = 64u * (uint32_t)unroll;
-        const size_t padded = (size_t)2 * (((t->tv.units + step - 1u) / step) * step) * sizeof(gw::u32x4);
+        const size_t padded = (size_t)2 * (((units + step - 1u) / step) * step) * sizeof(gw::u32x4);
         if (padded > t->lds_cap) sh.pipeline = 0;
     }
     size_t need = raw_need;
     if (sh.pipeline) {
         const uint32_t step = 64u * (uint32_t)unroll;
-        need = (size_t)2 * (((t->tv.units + step - 1u) / step) * step) * sizeof(gw::u32x4);
+        need = (size_t)2 * (((units + step - 1u) / step) * step) * sizeof(gw::u32x4);
     }
     if (lds && need > t->lds_cap) lds = false;
     sh.complement = (compl_ok && lds) ? 1 : 0;
@@ -146,7 +151,7 @@ gw::ScanShape scan_shape(const gw_table *t) {
     sh.lds_bytes = lds ? need : 0;
     sh.unroll = unroll;
     const int lds_limit = lds ? (int)(t->lds_cap / need) : 8;
-    const bool short_rows = t->tv.units <= 256u;  // N <= ~32 k: rows of one or two wave-steps
+    const bool short_rows = units <= 256u;  // N <= ~32 k: rows of one or two wave-steps
     int threads = t->opt_threads ? t->opt_threads
                                  : (one_per_cu ? (sh.pipeline ? 256 : 512) : (short_rows ? 256 : 1024));
     if (sh.pipeline && threads > 512) threads = 512;  // k_scan_cc_pipe is built for <= 512 threads
@@ -155,7 +160,7 @@ gw::ScanShape scan_shape(const gw_table *t) {
     sh.block_threads = threads;
     sh.grid_blocks = t->compute_units * per_cu;
     // short rows with every shape option left on auto: several rows per wave at a time, masks in registers
-    if (short_rows && t->opt_short_rows && !t->opt_unroll && !t->opt_threads && t->opt_mask_lds < 0 && t->opt_pipeline < 0 &&
+    if (!seg_units && short_rows && t->opt_short_rows && !t->opt_unroll && !t->opt_threads && t->opt_mask_lds < 0 && t->opt_pipeline < 0 &&
         t->opt_nt && t->opt_complement != 2) {
         sh.short_rows = 1;
         sh.complement = 0;
@@ -350,6 +355,7 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_mar) (void)hipFree(t->d_mar);
     if (t->d_marf) (void)hipFree(t->d_marf);
     if (t->d_cct) (void)hipFree(t->d_cct);
+    if (t->d_raw) (void)hipFree(t->d_raw);
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
     if (t->d_tally) (void)hipFree(t->d_tally);
@@ -633,6 +639,18 @@ int gw_table_get_case_control(gw_table *t, uint16_t *case_stream, uint16_t *ctrl
 
 // ------------------------------------------------------------------ scans
 
+// Units per column segment, or 0 for the one-pass scan.  Auto: segment only where the one-pass kernels
+// would have to read the masks through L2 (two masks beyond the LDS and no single-mask form: N > ~650 k
+// with arbitrary masks, N > ~1.3 M with complementary ones) -- 4096 units = 524 288 samples, both masks
+// 128 KiB, the shape of the c3 scan.
+static uint32_t column_segment(const gw_table *t) {
+    if (t->opt_segment > 0) return (uint32_t)t->opt_segment < t->tv.units ? (uint32_t)t->opt_segment : 0u;
+    if (t->opt_segment < 0 || t->opt_mask_lds == 0) return 0;
+    const gw::ScanShape sh = scan_shape(t);
+    if (sh.mask_in_lds || sh.short_rows) return 0;
+    return t->tv.units > 4096u ? 4096u : 0u;
+}
+
 int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_counts,
                                 void *d_stats, void *hip_stream) {
     if (!t || (!d_counts && n_snps)) return fail(GW_E_INVALID, "NULL argument");
@@ -642,10 +660,35 @@ int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     if (rc) return rc;
     if ((rc = gw_table_flush(t))) return rc;
     if ((rc = use_device(t))) return rc;
-    const gw::ScanShape sh = scan_shape(t);
-    GW_HIP(gw::launch_scan_cc(t->tv, t->d_case, t->d_ctrl, t->case_count, t->ctrl_count, snp_begin,
-                              (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh,
-                              pick_stream(t, hip_stream)));
+    hipStream_t stream = pick_stream(t, hip_stream);
+    const uint32_t seg = column_segment(t);
+    if (!seg) {
+        const gw::ScanShape sh = scan_shape(t);
+        GW_HIP(gw::launch_scan_cc(t->tv, t->d_case, t->d_ctrl, t->case_count, t->ctrl_count, snp_begin,
+                                  (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh, stream));
+        return GW_OK;
+    }
+    // Column-segmented scan: the masks of a segment fit the LDS, every segment streams its slice of all
+    // rows at the full-speed kernel's rate and adds six sums per row to a scratch array; a last small
+    // kernel turns the sums into counts and statistics.
+    const size_t raw_bytes = n_snps * 6u * sizeof(uint32_t);
+    if (raw_bytes > t->raw_bytes) {
+        if (t->d_raw) GW_HIP(hipFree(t->d_raw));
+        t->d_raw = nullptr;
+        t->raw_bytes = 0;
+        GW_HIP(hipMalloc((void **)&t->d_raw, raw_bytes));
+        t->raw_bytes = raw_bytes;
+    }
+    for (uint32_t u0 = 0; u0 < t->tv.units; u0 += seg) {
+        gw::TableView view = t->tv;
+        view.base = t->tv.base + u0;
+        view.units = std::min(seg, t->tv.units - u0);
+        const gw::ScanShape sh = scan_shape(t, view.units);
+        GW_HIP(gw::launch_scan_cc(view, t->d_case + u0, t->d_ctrl + u0, t->case_count, t->ctrl_count, snp_begin,
+                                  (uint32_t)n_snps, nullptr, nullptr, sh, stream, t->d_raw, u0 != 0));
+    }
+    GW_HIP(gw::launch_finish_raw(t->d_raw, (uint32_t)n_snps, t->case_count, t->ctrl_count, (uint32_t *)d_counts,
+                                 (double *)d_stats, stream));
     return GW_OK;
 }
 
@@ -1035,6 +1078,10 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
     case GW_OPT_SHORT_ROWS:
         t->opt_short_rows = v ? 1 : 0;
         return GW_OK;
+    case GW_OPT_COLUMN_SEGMENT:
+        if (v < -1 || v > (1 << 20)) return fail(GW_E_INVALID, "column_segment must be -1 (never), 0 (auto) or a unit count");
+        t->opt_segment = (int)v;
+        return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
         t->opt_prefilter = (int)v;
@@ -1057,6 +1104,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
+    case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }

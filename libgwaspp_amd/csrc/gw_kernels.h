@@ -43,7 +43,14 @@ struct ScanShape {
 hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
                           uint32_t case_count, uint32_t ctrl_count, uint64_t row_begin,
                           uint32_t n_rows, uint32_t *d_counts, double *d_stats,
-                          const ScanShape &shape, hipStream_t stream);
+                          const ScanShape &shape, hipStream_t stream,
+                          // column-segmented scan: tv / masks describe one segment of the columns and the six
+                          // sums per row go to d_raw[row][6] (added to it when raw_accumulate) -- not with
+                          // shape.complement or shape.short_rows
+                          uint32_t *d_raw = nullptr, bool raw_accumulate = false);
+// ... and its last step: counts[n][8] and stats[n][8] from the accumulated sums
+hipError_t launch_finish_raw(const uint32_t *d_raw, uint32_t n_rows, uint32_t case_count, uint32_t ctrl_count,
+                             uint32_t *d_counts, double *d_stats, hipStream_t stream);
 // sets hipFuncAttributeMaxDynamicSharedMemorySize on every scan instantiation
 hipError_t prepare_scan_kernels(size_t max_lds_bytes);
 

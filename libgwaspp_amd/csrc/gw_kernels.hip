@@ -159,10 +159,18 @@ struct ScanArgs {
     uint32_t case_count, ctrl_count;
     uint32_t *counts;
     double *stats;
+    uint32_t *raw;        // column-segmented scan: the six sums of this segment go here instead ([row][6])
+    int raw_accumulate;   // ... added to what earlier segments left
 };
 
 // ---- row epilogue shared by both scan kernels (table5.cpp:647-653 + section 5 of DESIGN.md)
 __device__ __forceinline__ void finish_row(const ScanArgs &a, uint32_t r, const uint32_t (&s)[6]) {
+    if (a.raw) {  // one segment of a column-segmented scan: partial sums only
+        uint32_t *o = a.raw + (size_t)r * 6u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o[j] = a.raw_accumulate ? o[j] + s[j] : s[j];
+        return;
+    }
     uint32_t ca[4], co[4];
     ca[2] = s[2]; ca[0] = s[0] - s[2]; ca[1] = s[1] - s[2];
     ca[3] = a.case_count - ca[0] - ca[1] - ca[2];
@@ -392,9 +400,10 @@ __global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 t
     const u32x4 *mcase = a.case_mask;
     const u32x4 *mctrl = a.ctrl_mask;
     if (MASK_LDS) {
-        for (uint32_t u = threadIdx.x; u < padded; u += blockDim.x) {
-            lds_masks[u] = a.case_mask[u];
-            lds_masks[padded + u] = a.ctrl_mask[u];
+        for (uint32_t u = threadIdx.x; u < padded; u += blockDim.x) {  // zero past `units` (a column segment's
+            const u32x4 zero = {0, 0, 0, 0};                              // masks continue with the next segment's)
+            lds_masks[u] = u < units ? a.case_mask[u] : zero;
+            lds_masks[padded + u] = u < units ? a.ctrl_mask[u] : zero;
         }
         __syncthreads();
         mcase = lds_masks;
@@ -651,10 +660,34 @@ static hipError_t launch_scan_u(const ScanArgs &args, const ScanShape &sh, hipSt
                           : launch_scan_inst<UNROLL, false, false>(args, sh, stream);
 }
 
+// the last step of a column-segmented scan: counts and statistics from the accumulated sums
+__global__ void k_finish_raw(ScanArgs a, const uint32_t *raw) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rows) return;
+    uint32_t s[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s[j] = raw[(size_t)r * 6u + j];
+    finish_row(a, r, s);
+}
+
+hipError_t launch_finish_raw(const uint32_t *d_raw, uint32_t n_rows, uint32_t case_count, uint32_t ctrl_count,
+                             uint32_t *d_counts, double *d_stats, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    ScanArgs a{};
+    a.n_rows = n_rows;
+    a.case_count = case_count;
+    a.ctrl_count = ctrl_count;
+    a.counts = d_counts;
+    a.stats = d_stats;
+    a.raw = nullptr;
+    hipLaunchKernelGGL(k_finish_raw, dim3((n_rows + 255u) / 256u), dim3(256), 0, stream, a, d_raw);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
                           uint32_t case_count, uint32_t ctrl_count, uint64_t row_begin,
                           uint32_t n_rows, uint32_t *d_counts, double *d_stats,
-                          const ScanShape &sh, hipStream_t stream) {
+                          const ScanShape &sh, hipStream_t stream, uint32_t *d_raw, bool raw_accumulate) {
     if (n_rows == 0) return hipSuccess;
     ScanArgs a;
     a.table = tv.base;
@@ -669,6 +702,8 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
     a.ctrl_count = ctrl_count;
     a.counts = d_counts;
     a.stats = d_stats;
+    a.raw = d_raw;
+    a.raw_accumulate = raw_accumulate ? 1 : 0;
     if (sh.short_rows) {  // rows of at most 256 units: a sub-wave of 16 (<= 80 units) or 32 lanes per row
         const bool pack = tv.n_samples < 65536u;
         if (tv.units <= 80u) {  // at most 5 steps of 16 lanes

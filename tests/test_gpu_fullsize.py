@@ -87,8 +87,9 @@ def test_full_size_properties(oracle, cfg):
 
 def test_million_sample_rows_use_the_single_mask_kernel(oracle):
     """N = 1 M: two masks (250 kB) exceed the 160 KiB LDS, one fits -> with complementary masks the
-    scan stages the case mask only; with a sample in neither group it falls back to masks read
-    through L2.  Same records either way, checked against the oracle on sampled rows."""
+    scan stages the case mask only; otherwise it walks the samples in column segments whose two masks
+    fit (or, with that switched off, reads the masks through L2).  Same records every way, checked
+    against the oracle on sampled rows."""
     if gw.device_count() == 0:
         pytest.fail("no HIP device visible")
     n, m = 1_000_000, 3000
@@ -99,9 +100,16 @@ def test_million_sample_rows_use_the_single_mask_kernel(oracle):
         cs, ct, nc, nt = t.get_case_control()
         counts, stats = t.scan_case_control()
         t.set_option(capi.OPT_COMPLEMENT, 0)
-        assert t.get_option(capi.OPT_MASK_IN_LDS) == 0
+        # two masks do not fit: the scan walks the samples in segments of 4096 units (both masks in LDS) ...
+        assert t.get_option(capi.OPT_MASK_IN_LDS) == 0 and t.get_option(capi.OPT_COLUMN_SEGMENT) == 4096
         c2, s2 = t.scan_case_control()
         assert np.array_equal(counts, c2) and np.array_equal(stats, s2)
+        # ... or, with segmentation off, in one pass with the masks read through L2
+        t.set_option(capi.OPT_COLUMN_SEGMENT, -1)
+        assert t.get_option(capi.OPT_COLUMN_SEGMENT) == 0
+        c3, s3 = t.scan_case_control()
+        assert np.array_equal(counts, c3) and np.array_equal(stats, s3)
+        t.set_option(capi.OPT_COLUMN_SEGMENT, 0)
         g = oracle.geometry_stream(n)
         for r in (0, 1, m // 2, m - 1):
             row = t.download_rows(r, 1)

@@ -475,3 +475,36 @@ def test_short_row_kernel(oracle, n, m):
         c4, s4 = t.scan_case_control()
         assert np.array_equal(c4, want_c)
         _assert_stats(s4, want_s)
+
+
+@pytest.mark.parametrize("n,m,seg", [(70_001, 130, 64), (70_001, 130, 300), (70_001, 77, 546), (20_000, 200, 100),
+                                     (9_000, 50, 1), (140_000, 40, 512)])
+def test_column_segmented_scan(oracle, n, m, seg):
+    """GW_OPT_COLUMN_SEGMENT: the samples are walked in segments (masks of a segment in LDS), six partial
+    sums per SNP accumulate, a last kernel finishes the rows -- the form very large cohorts (masks beyond
+    the LDS) take automatically.  Forced here on small tables: same records as the one-pass scan and the
+    oracle, for segments that do and do not divide the row, ranges, and kernel shapes."""
+    rng = np.random.default_rng(n + 3 * m + seg)
+    codes = _random_codes(rng, m, n, p_missing=0.02)
+    cs, ct, nc, nt = _random_masks(oracle, rng, n)
+    ts = oracle.pack_codes(codes, "stream")
+    want_counts, want_stats = oracle.scan_stream_cc(ts, oracle.geometry_stream(n), cs, ct, nc, nt)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        assert t.get_option(capi.OPT_COLUMN_SEGMENT) == 0   # auto: these tables scan in one pass
+        ref_counts, ref_stats = t.scan_case_control()
+        t.set_option(capi.OPT_COLUMN_SEGMENT, seg)
+        assert t.get_option(capi.OPT_COLUMN_SEGMENT) == seg
+        counts, stats = t.scan_case_control()
+        assert np.array_equal(counts, want_counts) and np.array_equal(counts, ref_counts)
+        _assert_stats(stats, want_stats)
+        assert np.array_equal(stats, ref_stats)
+        c2, s2 = t.scan_case_control(3, m - 5)
+        assert np.array_equal(c2, counts[3:m - 2]) and np.array_equal(s2, stats[3:m - 2])
+        for unroll, threads, pipe in ((2, 256, 1), (4, 512, 0), (1, 1024, 0)):
+            t.set_option(capi.OPT_UNROLL, unroll)
+            t.set_option(capi.OPT_BLOCK_THREADS, threads)
+            t.set_option(capi.OPT_PIPELINE, pipe)
+            c3, s3 = t.scan_case_control()
+            assert np.array_equal(c3, counts) and np.array_equal(s3, stats), (unroll, threads, pipe)
