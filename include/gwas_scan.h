@@ -238,10 +238,10 @@ int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows,
  * elapsed milliseconds since the matching gw_timer_start. */
 int gw_timer_start(gw_table *t, void *hip_stream);
 int gw_timer_stop(gw_table *t, void *hip_stream, float *elapsed_ms);
-/* The scan's own traversal of the table (one wave per row, 16 bytes per lane,
- * nt loads) with the arithmetic removed: the empirical streaming-read ceiling
- * SURVEY.md 8d asks to report next to the nominal 8 TB/s.  Returns the bytes
- * one launch loads. */
+/* A plain 16-byte-per-lane nt read of the whole table allocation (flat
+ * grid-stride, no arithmetic): the empirical streaming-read ceiling SURVEY.md 8d
+ * asks to report next to the nominal 8 TB/s.  Returns the bytes one launch
+ * loads (the rows with their padding). */
 int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read);
 int gw_synchronize(gw_table *t);
 

@@ -1026,8 +1026,8 @@ int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
     int rc = use_device(t);
     if (rc) return rc;
     GW_HIP(gw::launch_stream_probe(t->tv, t->d_misc + 8, t->compute_units, pick_stream(t, hip_stream)));
-    // bytes the probe loads: the sample-carrying units of both planes of every row
-    if (bytes_read) *bytes_read = t->tv.n_snps * 2ull * t->tv.units * 16ull;
+    // bytes the probe loads: the whole table allocation (rows with their padding)
+    if (bytes_read) *bytes_read = t->tv.n_snps * t->tv.row_stride_u * 16ull;
     return GW_OK;
 }
 

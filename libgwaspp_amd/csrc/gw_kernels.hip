@@ -20,7 +20,7 @@
 //                    list of SNP pairs, table5.cpp:749-800 / 806-895
 //   k_restride_*     the row packings of table5.cpp:277-365 / table3.cpp:260-325
 //   k_simulate*      data/simulate_data.cpp:150-235
-//   k_stream_probe   the scan's traversal with the arithmetic removed
+//   k_stream_probe   plain read of the table allocation (the empirical HBM ceiling)
 // (the all-pairs BOOST path is in gw_boost*.hip)
 #include "gw_kernels.h"
 
@@ -1327,40 +1327,32 @@ hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl
 }
 
 // ---------------------------------------------------------------------------
-// streaming-read probe: the empirical HBM read ceiling on this very buffer.
-// Same traversal as the scan (one wave per row, two planes, 2 units per lane in
-// flight, 512-thread persistent workgroups) with the arithmetic removed: every
-// 16-byte unit is loaded (nt) and folded into an XOR.
+// streaming-read probe: the empirical HBM read ceiling on this very buffer -- a
+// plain 16-byte-per-lane nt read of the whole table allocation (rows incl. their
+// padding), flat grid-stride, four loads in flight per lane, folded into an XOR.
+// Of the traversals compared in tools/read_patterns.hip this one reads 7.0-7.15
+// TB/s at every row length (a wave-per-row read drops to 4.4 TB/s at N = 10 k).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) k_stream_probe(const u32x4 *table, uint64_t row_stride_u,
-                                                      uint32_t plane_stride_u, uint32_t units,
-                                                      uint32_t n_rows, uint32_t *sink) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t gwave = blockIdx.x * waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t total_waves = gridDim.x * waves_per_block;
-    const uint32_t full = (units / 128u) * 128u;
+__global__ void __launch_bounds__(512) k_stream_probe(const u32x4 *table, uint64_t n_units, uint32_t *sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32x4 acc = {0, 0, 0, 0};
-    for (uint32_t r = gwave; r < n_rows; r += total_waves) {
-        const u32x4 *p0 = table + (uint64_t)r * row_stride_u;
-        const u32x4 *p1 = p0 + plane_stride_u;
-        for (uint32_t base = 0; base < full; base += 128u) {
-            const u32x4 a0 = ld_stream<true>(p0 + base + lane), b0 = ld_stream<true>(p1 + base + lane);
-            const u32x4 a1 = ld_stream<true>(p0 + base + 64u + lane), b1 = ld_stream<true>(p1 + base + 64u + lane);
-            acc ^= a0 ^ b0 ^ a1 ^ b1;
-        }
-        for (uint32_t u = full + lane; u < units; u += 64u) acc ^= ld_stream<true>(p0 + u) ^ ld_stream<true>(p1 + u);
+    for (; i + 3ull * stride < n_units; i += 4ull * stride) {
+        const u32x4 a = ld_stream<true>(table + i), b = ld_stream<true>(table + i + stride),
+                    c = ld_stream<true>(table + i + 2 * stride), d = ld_stream<true>(table + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
     }
+    for (; i < n_units; i += stride) acc ^= ld_stream<true>(table + i);
     uint32_t x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
-    if (lane == 0 && x == 0xDEADBEEFu) atomicAdd(sink, 1u);  // keeps the loads alive
+    if ((threadIdx.x & 63u) == 0 && x == 0xDEADBEEFu) atomicAdd(sink, 1u);  // keeps the loads alive
 }
 
 hipError_t launch_stream_probe(const TableView &tv, uint32_t *d_sink, int grid_blocks, hipStream_t stream) {
     if (tv.n_snps == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stream_probe, dim3(grid_blocks), dim3(512), 0, stream, tv.base, tv.row_stride_u,
-                       tv.plane_stride_u, tv.units, (uint32_t)tv.n_snps, d_sink);
+    hipLaunchKernelGGL(k_stream_probe, dim3(grid_blocks), dim3(512), 0, stream, tv.base,
+                       tv.n_snps * tv.row_stride_u, d_sink);
     return hipGetLastError();
 }
 
