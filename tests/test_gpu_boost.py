@@ -159,7 +159,8 @@ def _prefilter_table(rng, n, m, p_missing, low_maf):
 
 @pytest.mark.parametrize("n,m,p_missing,low_maf", [(600, 48, 0.0, False), (600, 48, 0.05, True), (6000, 64, 0.0, True),
                                                    (6000, 40, 0.02, False), (40_000, 40, 0.0, False),
-                                                   (40_000, 36, 0.0, True)])
+                                                   (40_000, 36, 0.0, True), (250_000, 24, 0.0, False),
+                                                   (250_000, 20, 0.01, True)])
 def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_maf):
     """gw_boost_screen without extremes may rule pairs out by the single-precision bound
     (GW_OPT_BOOST_PREFILTER): the hit list and its FP64 measures must not change, also for
