@@ -79,6 +79,18 @@ int label_from_header(uint16_t &header, unsigned enc) {
     return m.code;
 }
 
+// both allele letters at once: (first << 8 | second) -> 4 * a + b, or 16 where either is not in "ACGT"
+struct PairTable {
+    uint8_t v[65536];
+    PairTable() {
+        for (unsigned x = 0; x < 65536u; ++x) {
+            const unsigned a = kSymbols.v[x >> 8], b = kSymbols.v[x & 255u];
+            v[x] = (uint8_t)((a > 3u || b > 3u) ? 16u : 4u * a + b);
+        }
+    }
+};
+const PairTable kPairs;
+
 int pack_genotype_row(const char *begin, const char *end, uint32_t n_samples, bool block_layout,
                       uint16_t *row) {
     const uint32_t row_blocks = block_layout ? block_row_blocks(n_samples) : stream_row_blocks(n_samples);
@@ -87,22 +99,47 @@ int pack_genotype_row(const char *begin, const char *end, uint32_t n_samples, bo
     RowLabeller lab;
     uint16_t *lo = row + 1;
     uint16_t *hi = row + 1 + stream_blocks(n_samples);
-    uint32_t sample = 0;
-    for (const char *p = begin; p < end; p += 3, ++sample) {
-        if (sample >= n_samples) return -1;
-        const unsigned a = kSymbols.v[(unsigned char)p[0]];
-        const unsigned b = (p + 1 < end) ? kSymbols.v[(unsigned char)p[1]] : 4u;
-        if (a > 3u || b > 3u) continue;  // missing call: both bits stay 0
-        const int code = lab.code_for(4u * a + b);
+    const size_t len = (size_t)(end - begin);
+    const uint32_t n_text = (uint32_t)((len + 2u) / 3u);  // genotypes in the text (3 bytes each, the last may lack its delimiter)
+    if (n_text > n_samples) return -1;
+    // code of every genotype spelling seen so far in this row (0 = not yet seen / missing); slot 16 = missing
+    uint8_t code_of[17];
+    std::memset(code_of, 0, sizeof code_of);
+    bool seen[17];
+    std::memset(seen, 0, sizeof seen);
+    seen[16] = true;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(begin);
+    // whole genotypes whose two letters are both inside the text
+    const uint32_t n_full = (uint32_t)((len + 1u) / 3u) <= n_text ? (uint32_t)((len + 1u) / 3u) : n_text;
+    auto classify = [&](unsigned enc) -> int {  // first appearance of a spelling: the labelling automaton
+        const int code = lab.code_for(enc);
         if (code == 0) return -1;
-        if (block_layout) {
-            lo[sample >> 3] |= (uint16_t)(code << (2u * (sample & 7u)));
-        } else {
-            const uint16_t bit = (uint16_t)(1u << (sample & 15u));
-            if (code & 1) lo[sample >> 4] |= bit;
-            if (code & 2) hi[sample >> 4] |= bit;
+        code_of[enc] = (uint8_t)code;
+        seen[enc] = true;
+        return 0;
+    };
+    uint32_t sample = 0;
+    const uint32_t per_block = block_layout ? 8u : 16u;
+    while (sample < n_full) {
+        const uint32_t k_end = (n_full - sample < per_block) ? n_full - sample : per_block;
+        uint32_t w_lo = 0, w_hi = 0, w_blk = 0;
+        for (uint32_t k = 0; k < k_end; ++k, p += 3) {
+            const unsigned enc = kPairs.v[((unsigned)p[0] << 8) | p[1]];
+            if (!seen[enc] && classify(enc) != 0) return -1;
+            const uint32_t code = code_of[enc];
+            w_lo |= (code & 1u) << k;
+            w_hi |= (code >> 1) << k;
+            w_blk |= code << (2u * k);
         }
+        if (block_layout) {
+            lo[sample >> 3] = (uint16_t)w_blk;
+        } else {
+            lo[sample >> 4] = (uint16_t)w_lo;
+            hi[sample >> 4] = (uint16_t)w_hi;
+        }
+        sample += k_end;
     }
+    // a trailing one-letter genotype (text ends inside it) is a missing call: its bits stay 0
     row[0] = lab.header();
     return 0;
 }
