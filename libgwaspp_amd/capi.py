@@ -96,8 +96,7 @@ def library() -> C.CDLL:
     L.gw_table_destroy.argtypes = [vp]
     L.gw_table_geometry.argtypes = [vp, C.POINTER(Geometry)]
     L.gw_table_add_genotype_row.argtypes = [vp, C.c_uint64, vp, vp, C.c_char]
-    L.gw_table_add_genotype_rows.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
-                                             C.c_char, C.c_int]
+    L.gw_table_add_genotype_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, C.c_char, C.c_int]
     L.gw_table_flush.argtypes = [vp]
     L.gw_table_upload_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
     L.gw_table_download_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
@@ -222,9 +221,10 @@ class GwTable:
     def add_genotype_rows(self, snp_begin: int, texts, delim: bytes = b"\t", n_threads: int = 0):
         """Batch form: texts = list of bytes, one genotype row each, packed by n_threads host threads."""
         n = len(texts)
-        bufs = [C.create_string_buffer(t, len(t)) for t in texts]
-        begins = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
-        ends = (C.c_char_p * n)(*[C.cast(C.addressof(b) + len(t), C.c_char_p) for b, t in zip(bufs, texts)])
+        # the rows are read in place: `texts` keeps the bytes objects (and their buffers) alive for the call
+        addr = [C.cast(C.c_char_p(t), C.c_void_p).value or 0 for t in texts]
+        begins = (C.c_void_p * n)(*addr)
+        ends = (C.c_void_p * n)(*[a + len(t) for a, t in zip(addr, texts)])
         _check(self._L.gw_table_add_genotype_rows(self._h, snp_begin, n, begins, ends, delim, n_threads))
 
     def flush(self):
