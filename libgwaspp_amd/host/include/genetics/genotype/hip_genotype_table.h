@@ -124,6 +124,16 @@ protected:
     const CaseControlSet *installed;
     unsigned long installed_rev;
 
+    // pair getters: the reference's loops walk (i, j), (i, j+1), ... -- a run of pairs of the same first marker
+    // is fetched in one launch (the run grows x4 while the walk stays sequential, 1 .. 4096 pairs)
+    struct PairRun {
+        bool valid, masked;
+        uint first, second_begin, count, next_len;
+        std::vector<uint> plain, cases, ctrls;  // count x 16
+        PairRun() : valid(false), masked(false), first(0), second_begin(0), count(0), next_len(1) {}
+    } run;
+    const uint *pair_run(uint r1, uint r2, bool masked, const uint **ctrl_out);
+
     // operator()(r,c): one decoded row
     std::vector<ushort> row_cache;
     long row_cached;

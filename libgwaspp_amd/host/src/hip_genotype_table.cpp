@@ -69,6 +69,7 @@ HipGenotypeTable::~HipGenotypeTable() {
 
 void HipGenotypeTable::invalidate() {
     drop_prefetch();
+    run.valid = false;
     dist_count = cc_count = 0;
     row_cached = -1;
 }
@@ -226,6 +227,7 @@ void HipGenotypeTable::getGenotypeDistribution(uint rIdx, GenotypeDistribution &
 void HipGenotypeTable::install(CaseControlSet &ccs) {
     if (installed == &ccs && installed_rev == ccs.revision()) return;
     drop_prefetch();
+    run.valid = false;
     die_unless_ok(gw_table_set_case_control(tbl, ccs.stream_case_begin(), ccs.stream_control_begin(),
                                             ccs.stream_block_count(), ccs.getCaseCount(), ccs.getControlCount()),
                   "gw_table_set_case_control");
@@ -291,21 +293,62 @@ const double *HipGenotypeTable::getAssociationStatistics(uint rIdx) {
 
 // ----------------------------------------------------------------------- pairs
 
+// The pair (r1, r2) out of a run (r1, r2 .. r2 + count - 1) fetched in one launch.  The reference's pair loops
+// (computeBoost :393-486, ContingencyPerformance, contingency_debug) keep the first marker and advance the
+// second: a hit extends nothing, a miss right after the run's end fetches a run 4 x as long (up to 4096),
+// anything else starts over with a single pair -- random access costs what it did before.
+const uint *HipGenotypeTable::pair_run(uint r1, uint r2, bool masked, const uint **ctrl_out) {
+    const bool hit = run.valid && run.masked == masked && run.first == r1 && r2 >= run.second_begin &&
+                     r2 < run.second_begin + run.count;
+    if (!hit) {
+        settle();
+        const bool sequential = run.valid && run.masked == masked && run.first == r1 &&
+                                r2 == run.second_begin + run.count;
+        uint len = sequential ? std::min<uint>(run.next_len, 4096u) : 1u;
+        len = (uint)std::min<ulong>(len, (ulong)max_row - r2);
+        if (len == 0) len = 1;
+        std::vector<uint> pairs(2u * len);
+        for (uint k = 0; k < len; ++k) {
+            pairs[2u * k] = r1;
+            pairs[2u * k + 1u] = r2 + k;
+        }
+        if (masked) {
+            run.cases.resize(16u * len);
+            run.ctrls.resize(16u * len);
+            die_unless_ok(gw_pair_case_control_contingency(tbl, pairs.data(), len, run.cases.data(), run.ctrls.data()),
+                          "gw_pair_case_control_contingency");
+        } else {
+            run.plain.resize(16u * len);
+            die_unless_ok(gw_pair_contingency(tbl, pairs.data(), len, run.plain.data()), "gw_pair_contingency");
+        }
+        run.valid = true;
+        run.masked = masked;
+        run.first = r1;
+        run.second_begin = r2;
+        run.count = len;
+        run.next_len = sequential ? len * 4u : 4u;
+    }
+    const size_t off = 16u * (size_t)(r2 - run.second_begin);
+    if (masked) {
+        *ctrl_out = run.ctrls.data() + off;
+        return run.cases.data() + off;
+    }
+    return run.plain.data() + off;
+}
+
 void HipGenotypeTable::getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct) {
-    settle();
-    const uint pair[2] = {rIdx1, rIdx2};
     CONTIN_TABLE_T c;
-    die_unless_ok(gw_pair_contingency(tbl, pair, 1, c.contin), "gw_pair_contingency");
+    std::memcpy(c.contin, pair_run(rIdx1, rIdx2, false, nullptr), sizeof c.contin);
     ct.setMarkerAIndex(rIdx1);
     ct.setMarkerBIndex(rIdx2);
     ct.setContingency(c);
 }
 
 void HipGenotypeTable::pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABLE_T &ct) {
-    settle();
-    const uint pair[2] = {r1, r2};
-    die_unless_ok(gw_pair_case_control_contingency(tbl, pair, 1, cs.contin, ct.contin),
-                  "gw_pair_case_control_contingency");
+    const uint *ctrl = nullptr;
+    const uint *cases = pair_run(r1, r2, true, &ctrl);
+    std::memcpy(cs.contin, cases, sizeof cs.contin);
+    std::memcpy(ct.contin, ctrl, sizeof ct.contin);
 }
 
 void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs,
