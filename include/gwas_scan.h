@@ -190,6 +190,26 @@ int gw_scan_distribution(gw_table *t, uint64_t snp_begin, uint64_t n_snps, uint3
 int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps, void *d_dist,
                                 void *hip_stream);
 
+/* gw_scan_margins replaces the loop of computeMargins (algorithms/epistasis_func.cpp:706-721) over
+ * getCaseControlGenotypeDistribution(i, ccgd, m) (table5.cpp:703-747), i.e. the case/control counts of
+ * the selected table followed by computeMarginalInformation(cases, controls, nCases + nControls, m)
+ * (genotype/common_genotype_func.cpp:173-219), computed on the device.  The record has the layout of
+ * the reference's marginal_information (genotype/common_genotype.h:101-106, 192 bytes):
+ *   margins = cases + controls per genotype class {aa, ab, bb, xx};
+ *   marginal_entropy   = -sum p ln p over the 4 classes,      p = margin / n
+ *   marginal_entropy_y = -sum p ln p over 8 (class x status), p = count / n
+ *   pbc[g] / pbc[4+g]  = P(class | case) / P(class | control) = count / group size
+ *   pca[g] / pca[4+g]  = P(case | class) / P(control | class) = count / margin
+ * Entries of pbc / pca that belong to a class nobody has are ZERO here; the reference leaves them
+ * unwritten (quirk Q6), so compare only the written ones.  As in selectCaseControl
+ * (table5.cpp:531-548) a sample that is in both masks counts as a case only. */
+typedef struct gw_marginal_information {
+    uint32_t margins[4], cases[4], controls[4];
+    double marginal_entropy, marginal_entropy_y;
+    double pbc[8], pca[8];
+} gw_marginal_information;
+int gw_scan_margins(gw_table *t, uint64_t snp_begin, uint64_t n_snps, gw_marginal_information *out);
+
 /* ---- pairwise contingency (callers of the scan) -----
  * replaces getContingencyTable(i, j, ct) (table5.cpp:749-800) and
  * getCaseControlContingencyTable(i, j, ccs, ccct) (table5.cpp:806-895) for a

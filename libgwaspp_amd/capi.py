@@ -49,6 +49,19 @@ class DeviceInfo(C.Structure):
                 ("lds_bytes_per_cu", C.c_int), ("hbm_bytes", C.c_uint64), ("hbm_free_bytes", C.c_uint64)]
 
 
+class MarginalInformation(C.Structure):
+    """gw_marginal_information == the reference's marginal_information (common_genotype.h:101-106)."""
+    _fields_ = [("margins", C.c_uint32 * 4), ("cases", C.c_uint32 * 4), ("controls", C.c_uint32 * 4),
+                ("marginal_entropy", C.c_double), ("marginal_entropy_y", C.c_double),
+                ("pbc", C.c_double * 8), ("pca", C.c_double * 8)]
+
+
+MARGINAL_DTYPE = np.dtype([("margins", np.uint32, 4), ("cases", np.uint32, 4), ("controls", np.uint32, 4),
+                           ("marginal_entropy", np.float64), ("marginal_entropy_y", np.float64),
+                           ("pbc", np.float64, 8), ("pca", np.float64, 8)])
+assert MARGINAL_DTYPE.itemsize == C.sizeof(MarginalInformation) == 192
+
+
 def library_path() -> str:
     return _LIB
 
@@ -71,7 +84,7 @@ EXPORTS = [
     "gw_table_upload_rows", "gw_table_download_rows", "gw_table_get_headers", "gw_table_simulate",
     "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
-    "gw_scan_distribution_device", "gw_pair_contingency", "gw_pair_case_control_contingency",
+    "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
     "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected",
     "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_set_option",
     "gw_get_option", "gw_pack_genotype_row", "gw_header_assign", "gw_build_stream_mask", "gw_stream_blocks",
@@ -109,6 +122,7 @@ def library() -> C.CDLL:
     L.gw_scan_case_control_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp]
     L.gw_scan_distribution.argtypes = [vp, C.c_uint64, C.c_uint64, u32p]
     L.gw_scan_distribution_device.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp]
+    L.gw_scan_margins.argtypes = [vp, C.c_uint64, C.c_uint64, vp]
     L.gw_pair_contingency.argtypes = [vp, u32p, C.c_uint64, u32p]
     L.gw_pair_case_control_contingency.argtypes = [vp, u32p, C.c_uint64, u32p, u32p]
     L.gw_boost_screen.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, vp, C.c_uint64,
@@ -282,6 +296,13 @@ class GwTable:
         dist = np.zeros((n, 4), dtype=np.uint32)
         _check(self._L.gw_scan_distribution(self._h, snp_begin, n, _p32(dist)))
         return dist
+
+    def scan_margins(self, snp_begin: int = 0, n_snps: int | None = None) -> np.ndarray:
+        """marginal_information records (structured array, MARGINAL_DTYPE) of SNPs [snp_begin, +n)."""
+        n = self.n_snps - snp_begin if n_snps is None else n_snps
+        out = np.zeros(n, dtype=MARGINAL_DTYPE)
+        _check(self._L.gw_scan_margins(self._h, snp_begin, n, out.ctypes.data))
+        return out
 
     # ---- scans (device results; pointers are raw device addresses)
     def scan_case_control_device(self, snp_begin: int, n_snps: int, d_counts: int, d_stats: int | None,

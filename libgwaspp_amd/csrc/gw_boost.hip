@@ -118,6 +118,7 @@ __global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_in
         }
     }
     mar[r] = m;
+    if (!marf) return;
     // single-precision factors of the pre-screen's bound (not part of the reference's record)
     SnpMarginF f;
 #pragma unroll

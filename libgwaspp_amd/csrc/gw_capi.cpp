@@ -58,6 +58,7 @@ struct gw_table {
     uint32_t case_count = 0, ctrl_count = 0;
     bool masks_set = false;
     bool masks_complementary = false;  // every sample is a case or a control, none both
+    bool masks_overlap = false;        // some sample is in both masks (selectCaseControl then keeps it as a case only)
     std::vector<uint16_t> h_case, h_ctrl;  // reference stream packing, as handed in
 
     std::vector<uint16_t> headers;  // row header blocks (table5.cpp:363)
@@ -199,6 +200,12 @@ int check_range(const gw_table *t, uint64_t begin, uint64_t n) {
                     (unsigned long long)t->tv.n_snps);
     if (n > 0xFFFFFFFFull) return fail(GW_E_RANGE, "at most 2^32-1 SNPs per call");
     return GW_OK;
+}
+
+bool overlapping(const std::vector<uint16_t> &cs, const std::vector<uint16_t> &ct) {
+    for (size_t b = 0; b < cs.size(); ++b)
+        if (cs[b] & ct[b]) return true;
+    return false;
 }
 
 bool complementary(const std::vector<uint16_t> &cs, const std::vector<uint16_t> &ct, uint32_t n_samples) {
@@ -596,6 +603,7 @@ int gw_table_simulate_phenotype(gw_table *t, uint64_t seed) {
     t->ctrl_count = counts[1];
     t->masks_set = true;
     t->masks_complementary = complementary(t->h_case, t->h_ctrl, t->geo.n_samples);
+    t->masks_overlap = overlapping(t->h_case, t->h_ctrl);
     t->selected_valid = false;
     return GW_OK;
 }
@@ -621,6 +629,7 @@ int gw_table_set_case_control(gw_table *t, const uint16_t *case_stream, const ui
     t->ctrl_count = ctrl_count;
     t->masks_set = true;
     t->masks_complementary = complementary(t->h_case, t->h_ctrl, t->geo.n_samples);
+    t->masks_overlap = overlapping(t->h_case, t->h_ctrl);
     t->selected_valid = false;
     return GW_OK;
 }
@@ -998,6 +1007,37 @@ int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows,
         copy_plane(dst + 2u * cb, tb, src + 2u * t->wc, t->wt);
         copy_plane(dst + 2u * cb + tb, tb, src + 2u * t->wc + t->wt, t->wt);
     }
+    return GW_OK;
+}
+
+// marginal_information of SNPs [snp_begin, +n) as getCaseControlGenotypeDistribution(r, ccgd, m) returns it
+// after selectCaseControl (table5.cpp:703-747 -> common_genotype_func.cpp:173-219)
+int gw_scan_margins(gw_table *t, uint64_t snp_begin, uint64_t n_snps, gw_marginal_information *out) {
+    static_assert(sizeof(gw_marginal_information) == sizeof(gw::SnpMargin) && sizeof(gw::SnpMargin) == 192,
+                  "marginal_information record layout");
+    if (!t || (!out && n_snps)) return fail(GW_E_INVALID, "NULL argument");
+    if (!t->masks_set)
+        return fail(GW_E_STATE, "gw_table_set_case_control must be called before gw_scan_margins");
+    int rc = check_range(t, snp_begin, n_snps);
+    if (rc) return rc;
+    if (n_snps == 0) return GW_OK;
+    if ((rc = gw_table_flush(t))) return rc;
+    if ((rc = use_device(t))) return rc;
+    const size_t bytes = n_snps * sizeof(gw::SnpMargin);
+    // A sample in both masks is a case only once the table is "selected" (table5.cpp:531-548): that rare
+    // case goes through the compaction's own margins; otherwise one scan of the range is all it takes.
+    if (t->selected_valid || t->masks_overlap) {
+        if ((rc = ensure_selected(t))) return rc;
+        GW_HIP(hipMemcpyAsync(out, t->d_mar + snp_begin, bytes, hipMemcpyDeviceToHost, t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));
+        return GW_OK;
+    }
+    if ((rc = ensure_scratch(t, n_snps * GW_N_COUNTS * sizeof(uint32_t), bytes))) return rc;
+    if ((rc = gw_scan_case_control_device(t, snp_begin, n_snps, t->d_scratch32, nullptr, nullptr))) return rc;
+    GW_HIP(gw::launch_margins(t->d_scratch32, (uint32_t)n_snps, t->case_count + t->ctrl_count,
+                              reinterpret_cast<gw::SnpMargin *>(t->d_scratch64), nullptr, t->stream));
+    GW_HIP(hipMemcpyAsync(out, t->d_scratch64, bytes, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
     return GW_OK;
 }
 

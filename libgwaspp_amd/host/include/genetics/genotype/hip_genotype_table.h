@@ -25,6 +25,7 @@
 #include "genetics/genotype/geno_table.h"
 
 struct gw_table;  // include/gwas_scan.h
+struct gw_marginal_information;
 
 namespace libgwaspp {
 namespace genetics {
@@ -108,7 +109,8 @@ protected:
     // result caches (host)
     std::vector<uint> dist_cache, cc_cache;
     std::vector<double> stat_cache;
-    ulong dist_begin, dist_count, cc_begin, cc_count;
+    ulong dist_begin, dist_count, cc_begin, cc_count, mar_begin;
+    std::vector<gw_marginal_information> mar_cache;  // a window of device-computed marginal_information
     bool prefetch;
     struct Ahead {
         std::future<int> done;

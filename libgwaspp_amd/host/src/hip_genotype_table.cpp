@@ -37,7 +37,7 @@ inline void to_freq(const uint *c, frequency_table &ft) {
 
 HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
     : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
-      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), prefetch(true), installed(nullptr),
+      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), mar_begin(0), prefetch(true), installed(nullptr),
       installed_rev(0), row_cached(-1) {
     initialize();
 }
@@ -71,6 +71,7 @@ void HipGenotypeTable::invalidate() {
     drop_prefetch();
     run.valid = false;
     dist_count = cc_count = 0;
+    mar_cache.clear();
     row_cached = -1;
 }
 
@@ -237,6 +238,7 @@ void HipGenotypeTable::install(CaseControlSet &ccs) {
     nControlCount = ccs.getControlCount();
     nIndivids = nCaseCount + nControlCount;
     cc_count = 0;
+    mar_cache.clear();
 }
 
 void HipGenotypeTable::selectCaseControl(CaseControlSet &ccs) {
@@ -282,8 +284,25 @@ void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControl
 
 void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd,
                                                           marginal_information &m) {
-    getCaseControlGenotypeDistribution(rIdx, ccgd);
-    computeMarginalInformation(*ccgd.getCaseDistribution(), *ccgd.getControlDistribution(), nIndivids, m);
+    // table5.cpp:703-747: the counts of the selected table + computeMarginalInformation, here computed on the
+    // device for a whole window of rows at once (gw_scan_margins); computeMargins (epistasis_func.cpp:706-721)
+    // walks r = 0 .. M-1 in order
+    static_assert(sizeof(marginal_information) == sizeof(gw_marginal_information), "marginal_information layout");
+    if (rIdx < mar_begin || rIdx >= mar_begin + mar_cache.size()) {
+        if (!installed) {
+            std::fprintf(stderr, "HipGenotypeTable: no CaseControlSet selected\n");
+            std::abort();
+        }
+        settle();
+        const ulong begin = (rIdx / window) * (ulong)window;
+        const ulong n = std::min<ulong>(window, (ulong)max_row - begin);
+        mar_cache.resize(n);
+        die_unless_ok(gw_scan_margins(tbl, begin, n, mar_cache.data()), "gw_scan_margins");
+        mar_begin = begin;
+    }
+    std::memcpy(&m, &mar_cache[rIdx - mar_begin], sizeof m);
+    ccgd.setCaseDistribution(m.cases);
+    ccgd.setControlDistribution(m.controls);
 }
 
 const double *HipGenotypeTable::getAssociationStatistics(uint rIdx) {

@@ -32,7 +32,7 @@ using namespace libgwaspp::algorithms;
 static void usage() {
     std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] [--scan-window ROWS] [--no-prefetch] "
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
-                 "--valid-geno|--contin-debug|--epi-debug|--test-boost-epi|--contin-perform|--assoc\n";
+                 "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--contin-perform|--assoc\n";
     std::exit(2);
 }
 
@@ -121,6 +121,26 @@ int main(int argc, char **argv) {
                     print_table(*out, *t->getControlContingencyTable());
                 }
             }
+    } else if (mode == "--margins") {
+        // computeMargins' loop (epistasis_func.cpp:706-721): the three-argument getter after selectCaseControl
+        CaseControlSet &ccs = *gd.getCaseControlSet();
+        CaseControlGenotypeDistribution ccgd;
+        gt.selectCaseControl(ccs);
+        char buf[64];
+        for (int i = 0; i < M; ++i) {
+            marginal_information m;
+            std::memset(&m, 0xFF, sizeof m);  // the getter must fill every field
+            gt.getCaseControlGenotypeDistribution(i, ccgd, m);
+            *out << i;
+            for (int g = 0; g < 4; ++g) *out << "\t" << m.margins.freq[g];
+            for (int g = 0; g < 4; ++g) *out << "\t" << ccgd.getCaseDistribution()->freq[g];
+            for (int g = 0; g < 4; ++g) *out << "\t" << ccgd.getControlDistribution()->freq[g];
+            std::snprintf(buf, sizeof buf, "\t%.17g\t%.17g", m.dMarginalEntropy, m.dMarginalEntropy_Y);
+            *out << buf;
+            for (int k = 0; k < 8; ++k) { std::snprintf(buf, sizeof buf, "\t%.17g", m.dPbc[k]); *out << buf; }
+            for (int k = 0; k < 8; ++k) { std::snprintf(buf, sizeof buf, "\t%.17g", m.dPca[k]); *out << buf; }
+            *out << "\n";
+        }
     } else if (mode == "--test-boost-epi") {
         computeBoost(&gd, out);
     } else if (mode == "--contin-perform") {
