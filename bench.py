@@ -2,28 +2,37 @@
 """bench.py -- SNPs/s of the per-SNP case/control association scan on MI355X.
 
 A "step" is one pass of the hot path (fused counts + MAF + HWE + chi-square
-kernel, one launch) over the rank's whole genotype table, inputs resident in
-HBM.  Default workload = BASELINE.json configs[2] ("c3"): 500 000 samples x
-1 000 000 SNPs (125 GB of 2-bit genotypes) on one GPU -- the configuration the
-north-star target (>= 70 % of the HBM-read roofline) is quoted on.
+kernel) over the whole genotype table of the workload, inputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4|n10k|c5]
+
+N = 1 (default): BASELINE.json configs[2] ("c3"): 500 000 samples x 1 000 000
+SNPs (125 GB of 2-bit genotypes) on one GPU -- the configuration the north-star
+target (>= 70 % of the HBM-read roofline) is quoted on.
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU.  SNP rows shard by contiguous ranges (weak scaling: every
-rank scans its own full-size shard, global SNP index = rank * M + row), and the
-one exchange step of the path -- the gather of per-SNP statistics to rank 0
-over RCCL/xGMI -- runs chunk-wise on RCCL's stream under the next chunk's scan.
+one rank per GPU, and runs BASELINE.json configs[3] ("c4"): the SAME 1 M-SNP
+table sharded by contiguous SNP ranges (rank r holds and scans
+shard.snp_range(1 000 000, r, N); strong scaling), and the one exchange step of
+the path -- the gather of the 96-byte per-SNP records to rank 0 over RCCL/xGMI
+-- inside every timed step (it runs on RCCL's stream under the next step's
+scan; every step's records have reached rank 0 before the clock stops).
+`--scaling weak` keeps the full-size table on every rank instead and says so in
+config.workload.  There is no silent fallback anywhere: a collective that
+fails ends the run non-zero.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = SNPs all ranks
 processed / max-over-ranks wall time; "roofline" for the scan kernel from HIP
 events on the launching stream; "cpu_baseline" = the CPU oracle's faithful
-single-thread port timed on this host on a bounded sample of the same table.
+single-thread port timed on this host on a bounded sample of the same table
+(+ the whole of configs[0], 10 k x 50 k, on the CPU path).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,10 +41,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (n_samples, n_snps per GPU, text)
+    # name: (n_samples, n_snps in the whole job, text)
     "c1": (10_000, 50_000, "c1: 10k samples x 50k SNPs case/control chi2 scan (plumbing size)"),
     "c2": (100_000, 500_000, "c2: 100k samples x 500k SNPs, per-SNP 3x3 contingency + chi2"),
     "c3": (500_000, 1_000_000, "c3: 500k samples x 1M SNPs, MAF + HWE + case/control chi2 combined scan"),
+    "c4": (500_000, 1_000_000, "c4: 500k samples x 1M SNPs SNP-sharded across the GPUs, RCCL gather over xGMI"),
     # not a BASELINE.json config: the size of a typical cohort (short rows -> the sub-wave-per-row kernel)
     "n10k": (10_000, 1_000_000, "10k samples x 1M SNPs, MAF + HWE + case/control chi2 combined scan (short rows)"),
     # configs[4]: all SNP pairs; BASELINE.json gives no sample count for it -> 10 k (5 k / 5 k), stated
@@ -45,6 +55,7 @@ MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the ~2.5 PFLOP/s bf16 peak (MI
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 0x5EED
 RECORD_BYTES = 32 + 64  # counts uint32[8] + stats float64[8] per SNP
+KERNEL_SOURCE = os.path.join(ROOT, "libgwaspp_amd", "csrc", "gw_kernels.hip")
 
 
 def parse_args():
@@ -52,11 +63,22 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--snps", type=int, default=0, help="override SNPs per GPU (debug)")
-    ap.add_argument("--chunks", type=int, default=4, help="scan/gather pipeline chunks when N > 1")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default: c3 on one GPU, c4 (= c3's table sharded) on several")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the workload's SNPs are sharded over the ranks (BASELINE config 4); "
+                         "weak = every rank scans a full-size table of its own")
+    ap.add_argument("--snps", type=int, default=0, help="override the job's SNP count (debug)")
+    ap.add_argument("--chunks", type=int, default=0, help="scan/gather pieces per step (0 = auto: 1, or 2 when N > 1)")
+    ap.add_argument("--buffers", type=int, default=3, help="N > 1: record buffers per piece (gathers in flight)")
+    ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
+                    help="N > 1: RCCL gather to rank 0 (grouped send/recv, one xGMI link per peer) or all_gather")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 debugging aid for a one-GPU box: every rank opens device 0, the process group is gloo "
+                         "and the records travel through host memory -- exercises the sharding / buffering logic, "
+                         "NOT a measurement (the JSON line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side measurement of c2")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (c2, n10k, c5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work")
     ap.add_argument("--unroll", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
@@ -66,14 +88,46 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass, or None."""
+def kernel_source_sha16():
+    with open(KERNEL_SOURCE, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def pmc_traffic(workload, kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json) -- only if
+    that figure was taken for the kernel instantiation that ran here AND from the kernel source as it is
+    now (each entry is stamped with both); otherwise (None, why)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+            e = json.load(f).get(workload)
+    except Exception as ex:
+        return None, f"profiles/pmc_traffic.json unreadable: {ex}"
+    if not e:
+        return None, f"no PMC entry for workload {workload}"
+    if e.get("kernel") != kernel_name:
+        return None, f"PMC entry is for {e.get('kernel')}, this run launched {kernel_name}"
+    if e.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, (f"PMC entry was taken at kernel source {e.get('kernel_source_sha16')} (git {e.get('git')}), "
+                      f"the source is now {kernel_source_sha16()}")
+    return e.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json[{workload}], git {e.get('git')}"
+
+
+def host_threads():
+    # the GPU box gives a one-GPU job a 16-core share of its host (os.cpu_count() shows all of it)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    return max(1, min(threads, 16))
 
 
 def cpu_baseline(table, n_samples, seconds):
@@ -101,12 +155,7 @@ def cpu_baseline(table, n_samples, seconds):
     gpu_counts, gpu_stats = table.scan_case_control(0, sample)
     parity = bool(np.array_equal(gpu_counts, counts)) and bool(
         np.allclose(gpu_stats, stats, rtol=1e-10, atol=1e-12))
-    # the GPU box gives a one-GPU job a 16-core share of its host (os.cpu_count() shows all of it)
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        threads = os.cpu_count() or 1
-    threads = max(1, min(threads, 16))
+    threads = host_threads()
     t1 = time.perf_counter()
     mt_passes = 0
     while mt_passes < 2 or time.perf_counter() - t1 < 2.0:
@@ -123,6 +172,59 @@ def cpu_baseline(table, n_samples, seconds):
                                   "GBps": sample * bytes_per_snp / dt_mt / 1e9,
                                   "note": "hardware popcount, pthreads over SNP ranges"},
     }
+
+
+def cpu_baseline_c1(seconds=4.0):
+    """BASELINE.json configs[0] as stated: the WHOLE 10 k x 50 k case/control scan on the CPU path
+    (simulate_data.cpp-shaped input generated on the GPU and downloaded in the reference's stream
+    packing), faithful single-thread LUT port and all host cores; the GPU scan of the same table is
+    checked against it and timed beside it."""
+    import numpy as np
+    import libgwaspp_amd as gw
+    from oracle import oracle
+
+    n, m, text = WORKLOADS["c1"]
+    g = oracle.geometry_stream(n)
+    with gw.GwTable(n, m) as t:
+        t.simulate(SEED, 0, 0)
+        t.simulate_phenotype(SEED)
+        rows = t.download_rows(0, m)
+        cs, ct, nc, nt = t.get_case_control()
+        gpu_counts, gpu_stats = t.scan_case_control()
+        import torch
+        buf = torch.empty(m * RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        base = buf.data_ptr()
+        for _ in range(5):
+            t.scan_case_control_device(0, m, base, base + m * 32, None)
+        t.synchronize()
+        t.timer_start(None)
+        for _ in range(50):
+            t.scan_case_control_device(0, m, base, base + m * 32, None)
+        gpu_ms = t.timer_stop(None) / 50
+        gpu_kernel = t.last_scan_kernel()
+    t0 = time.perf_counter()
+    passes = 0
+    while passes < 2 or time.perf_counter() - t0 < seconds:
+        counts, stats = oracle.scan_stream_cc(rows, g, cs, ct, nc, nt)
+        passes += 1
+    dt = (time.perf_counter() - t0) / passes
+    threads = host_threads()
+    t1 = time.perf_counter()
+    mt = 0
+    while mt < 3 or time.perf_counter() - t1 < 1.0:
+        oracle.scan_stream_cc(rows, g, cs, ct, nc, nt, threads=threads)
+        mt += 1
+    dt_mt = (time.perf_counter() - t1) / mt
+    parity = bool(np.array_equal(gpu_counts, counts)) and bool(np.allclose(gpu_stats, stats, rtol=1e-10, atol=1e-12))
+    return {"workload": text, "value": m / dt, "unit": "SNPs/s", "cores": 1, "kind": "port",
+            "sample": f"all {m} SNPs x {n} samples, {passes} passes, faithful single-thread LUT-popcount port",
+            "seconds_per_scan": dt, "GBps": m * (n / 4.0) / dt / 1e9, "gpu_parity": parity,
+            "best_effort_all_cores": {"value": m / dt_mt, "unit": "SNPs/s", "cores": threads,
+                                      "seconds_per_scan": dt_mt, "GBps": m * (n / 4.0) / dt_mt / 1e9},
+            "gpu_same_table": {"ms_per_scan": gpu_ms, "value": m / (gpu_ms * 1e-3), "unit": "SNPs/s",
+                               "achieved_GBps": m * (n / 4.0) / (gpu_ms * 1e-3) / 1e9,
+                               "frac": m * (n / 4.0) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": gpu_kernel,
+                               "note": "0.125 GB table, resident in the 256 MB Infinity Cache"}}
 
 
 def side_workload(name, steps, warmup):
@@ -145,10 +247,10 @@ def side_workload(name, steps, warmup):
         ms = t.timer_stop(None) / steps
         gbps = m * (n / 4.0) / (ms * 1e-3) / 1e9
         return {"workload": text, "ms_per_step": ms, "value": m / (ms * 1e-3), "unit": "SNPs/s",
-                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "kernel": t.last_scan_kernel()}
 
 
-def bench_pairs(args, rank, world, local_rank, dist):
+def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, with_cpu_baseline=True):
     """--workload c5: the BOOST / KSA pre-screen over every SNP pair (computeBoost,
     algorithms/epistasis_func.cpp:349-506).  A step = one screen of the whole pair space; the
     triangle is sharded over the ranks by row blocks (strong scaling: the pair count is fixed),
@@ -158,8 +260,10 @@ def bench_pairs(args, rank, world, local_rank, dist):
     import libgwaspp_amd as gw
     from libgwaspp_amd import shard
 
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     n_samples, n_snps, text = WORKLOADS["c5"]
-    if args.snps:
+    if args.snps and args.workload == "c5":
         n_snps = args.snps
     table = gw.GwTable(n_samples, n_snps, device=local_rank)
     table.simulate(SEED, 0, 0)
@@ -191,13 +295,13 @@ def bench_pairs(args, rank, world, local_rank, dist):
             dist.all_gather_into_tensor(out, buf)
         return total, pairs
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         n_hits, n_pairs = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -211,13 +315,13 @@ def bench_pairs(args, rank, world, local_rank, dist):
         elapsed, n_pairs, n_hits = float(tmax.item()), int(agg[1].item()), int(agg[2].item())
     out = None
     if rank == 0:
-        per_step = elapsed / args.steps
+        per_step = elapsed / steps
         # no missing calls in the synthetic table: 4 counted corners per pair and group, each a dot product
         # of 0/1 class vectors over the group's samples = n_samples MACs per corner -> int8 MFMA
         macs = n_pairs * 4.0 * n_samples
         out = {
             "metric": "SNP pairs/sec BOOST KSA pre-screen", "value": n_pairs / per_step, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i8 x i8 -> i32 (counts), f64 (measure)",
             "data": "synthetic",
             "config": {"workload": text, "n_samples": n_samples, "n_snps": n_snps, "pairs": n_pairs,
@@ -231,7 +335,7 @@ def bench_pairs(args, rank, world, local_rank, dist):
                          "note": "algorithmic MACs only (sample padding to 1024 per group not counted)"},
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and with_cpu_baseline and not args.no_cpu_baseline:
             from oracle import oracle
             k = 1200  # ~7 x 10^5 pairs, a few seconds of one host core
             rows = table.download_rows(0, k)
@@ -258,27 +362,43 @@ def bench_pairs(args, rank, world, local_rank, dist):
 
 def main():
     args = parse_args()
-    import numpy as np
-    import torch
-    import libgwaspp_amd as gw
-    from libgwaspp_amd import capi
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus) and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available() or gw.device_count() == 0:
+
+    import torch
+    # before any GPU call: one rank per GPU means this node must show at least LOCAL_RANK + 1 devices
+    # (torch.cuda.device_count() does not initialise the GPU)
+    n_visible = torch.cuda.device_count()
+    if n_visible == 0:
+        raise SystemExit("bench.py: no GPU visible; the scan has no CPU fallback")
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    if rehearse:
+        local_rank = 0
+    if local_rank >= n_visible:
+        raise SystemExit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own: this node shows "
+                         f"{n_visible} device(s) for {world} ranks -- one rank per GPU, nothing was launched")
+    import numpy as np  # noqa: F401
+    import libgwaspp_amd as gw
+    from libgwaspp_amd import capi, shard
+
+    if gw.device_count() == 0:
         raise SystemExit("bench.py: no GPU visible; the scan has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
-    if args.workload == "c5":
+    workload = args.workload or ("c3" if world == 1 else "c4")
+    if workload == "c5":
         out = bench_pairs(args, rank, world, local_rank, dist)
         if world > 1:
             dist.barrier()
@@ -287,10 +407,25 @@ def main():
             print(json.dumps(out))
         return
 
-    n_samples, n_snps, wl_text = WORKLOADS[args.workload]
+    n_samples, n_job, wl_text = WORKLOADS[workload]
     if args.snps:
-        n_snps = args.snps
-    table = gw.GwTable(n_samples, n_snps, device=local_rank)
+        n_job = args.snps
+    strong = world > 1 and args.scaling == "strong"
+    if rehearse:
+        wl_text = "REHEARSAL ON ONE GPU (gloo, host-staged exchange; not a measurement): " + wl_text
+    if world > 1 and not strong:
+        # the explicit weak-scaling form: a full-size table on every rank, global SNP index = rank * M + row
+        wl_text = f"WEAK-SCALING variant (not a BASELINE config): every rank scans its own {n_job}-SNP table; " + wl_text
+        begin, n_local, n_total = rank * n_job, n_job, n_job * world
+    elif world > 1:
+        begin, end = shard.snp_range(n_job, rank, world)  # BASELINE config 4: the job's SNPs sharded
+        n_local, n_total = end - begin, n_job
+    else:
+        begin, n_local, n_total = 0, n_job, n_job
+    n_cap = max(shard.snp_range(n_total, r, world)[1] - shard.snp_range(n_total, r, world)[0]
+                for r in range(world)) if strong else n_local  # equal buffer sizes for the collective
+
+    table = gw.GwTable(n_samples, n_local, device=local_rank)
     if args.unroll:
         table.set_option(capi.OPT_UNROLL, args.unroll)
     if args.threads:
@@ -302,21 +437,27 @@ def main():
     if args.nt >= 0:
         table.set_option(capi.OPT_NONTEMPORAL, args.nt)
     t_setup = time.perf_counter()
-    table.simulate(SEED, rank * n_snps, 0)   # no missing calls, like data/simulate_data.cpp
+    table.simulate(SEED, begin, 0)           # rows of ONE table: row r of this rank = global SNP begin + r
     table.simulate_phenotype(SEED)           # identical masks on every rank (same seed)
     t_setup = time.perf_counter() - t_setup
 
-    # result buffers (torch = device memory + streams + RCCL plumbing)
-    from libgwaspp_amd import shard
-    bounds = shard.chunk_bounds(n_snps, args.chunks if world > 1 else 1)
+    # result buffers (torch = device memory + streams + RCCL plumbing).  A step is cut into n_chunks pieces;
+    # each piece has `n_buf` record buffers used round-robin over the steps, so a scan only ever waits for
+    # the gather that used its buffer n_buf steps ago.
+    n_chunks = args.chunks if args.chunks > 0 else (2 if world > 1 else 1)
+    bounds = shard.chunk_bounds(n_cap, n_chunks)
     n_chunks = len(bounds) - 1
-    bufs, gathers = [], []
+    n_buf = max(1, args.buffers) if world > 1 else 1
+    bufs, gathers, allgather_out = [], [], []
     for c in range(n_chunks):
-        rows = bounds[c + 1] - bounds[c]
-        bufs.append(torch.empty(rows * RECORD_BYTES, dtype=torch.uint8, device="cuda"))
-        if world > 1 and rank == 0:
-            gathers.append([torch.empty(rows * RECORD_BYTES, dtype=torch.uint8, device="cuda")
-                            for _ in range(world)])
+        cap = bounds[c + 1] - bounds[c]
+        bufs.append([torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(n_buf)])
+        if world > 1 and args.collective == "gather" and rank == 0 and not rehearse:
+            gathers.append([[torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(world)]
+                            for _ in range(n_buf)])
+        if world > 1 and args.collective == "all_gather":
+            allgather_out.append([torch.empty(world * cap * RECORD_BYTES, dtype=torch.uint8, device="cuda")
+                                  for _ in range(n_buf)])
     # An explicit (non-default) torch stream: the scans are launched on it through the C-ABI and RCCL
     # orders each gather behind it.  (The default stream's handle is 0, which the C-ABI reads as "the
     # table's own stream" -- RCCL would then not wait for the scan.)
@@ -325,47 +466,50 @@ def main():
     sptr = stream.cuda_stream
     assert sptr != 0
 
-    # the exchange step: per-SNP records to rank 0.  gather = grouped send/recv in RCCL, each
-    # slice over its own xGMI link; if this RCCL build refuses gather, fall back to all_gather
-    # (ring, per-link bound) rather than abort the run.
-    collective = {"name": "gather"}
-    allgather_out = None
+    def scan_piece(c, b):
+        lo, hi = min(bounds[c], n_local), min(bounds[c + 1], n_local)  # a shard one row short scans one row less
+        cap = bounds[c + 1] - bounds[c]
+        base = bufs[c][b].data_ptr()
+        if hi > lo:
+            table.scan_case_control_device(lo, hi - lo, base, base + cap * 32, sptr)
 
-    def exchange(c):
-        nonlocal allgather_out
-        if collective["name"] == "gather":
-            try:
-                _, w = shard.gather_records(dist, bufs[c], rank, world, dst=0, async_op=True,
-                                            out=gathers[c] if rank == 0 else None)
-                return w
-            except (RuntimeError, NotImplementedError) as e:
-                if rank == 0:
-                    print(f"bench.py: dist.gather unavailable ({e}); using all_gather_into_tensor", file=sys.stderr)
-                collective["name"] = "all_gather"
-        if allgather_out is None:
-            allgather_out = [torch.empty(world * b.numel(), dtype=torch.uint8, device="cuda") for b in bufs]
-        return dist.all_gather_into_tensor(allgather_out[c], bufs[c], async_op=True)
+    # the exchange step: per-SNP records to rank 0.  gather = grouped send/recv in RCCL, every peer's
+    # slice over its own xGMI link.  An exception here ends the run (no fallback).
+    rehearsal_last = {}
 
-    # chunk c's records travel while the following chunks (and the next step) are scanned; a chunk's
-    # buffer is only re-used once its previous exchange has completed (GPU-side stream wait)
-    pending = [None] * n_chunks
+    def exchange(c, b):
+        if rehearse:  # gloo, through host memory, synchronous: logic check only
+            stream.synchronize()
+            got, _ = shard.gather_records(dist, bufs[c][b].cpu(), rank, world, dst=0)
+            if rank == 0:
+                rehearsal_last[c] = got
+            return None
+        if args.collective == "gather":
+            _, w = shard.gather_records(dist, bufs[c][b], rank, world, dst=0, async_op=True,
+                                        out=gathers[c][b] if rank == 0 else None)
+            return w
+        return dist.all_gather_into_tensor(allgather_out[c][b], bufs[c][b], async_op=True)
+
+    pending = [[None] * n_buf for _ in range(n_chunks)]
+    step_no = [0]
 
     def step():
+        b = step_no[0] % n_buf
+        step_no[0] += 1
         for c in range(n_chunks):
-            if pending[c] is not None:
-                pending[c].wait()
-                pending[c] = None
-            rows = bounds[c + 1] - bounds[c]
-            base = bufs[c].data_ptr()
-            table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
+            if pending[c][b] is not None:
+                pending[c][b].wait()  # GPU-side: the scan stream waits for the gather that last read this buffer
+                pending[c][b] = None
+            scan_piece(c, b)
             if world > 1:
-                pending[c] = exchange(c)
+                pending[c][b] = exchange(c, b)
 
     def drain():
         for c in range(n_chunks):
-            if pending[c] is not None:
-                pending[c].wait()
-                pending[c] = None
+            for b in range(n_buf):
+                if pending[c][b] is not None:
+                    pending[c][b].wait()
+                    pending[c][b] = None
 
     for _ in range(args.warmup):
         step()
@@ -386,7 +530,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -398,18 +542,16 @@ def main():
         table.timer_start(sptr)
         for _ in range(args.steps):
             for c in range(n_chunks):
-                rows = bounds[c + 1] - bounds[c]
-                base = bufs[c].data_ptr()
-                table.scan_case_control_device(bounds[c], rows, base, base + rows * 32, sptr)
+                scan_piece(c, 0)
         kernel_ms_total = table.timer_stop(sptr)
 
     out = None
     if rank == 0:
         geo = table.geometry
-        total_snps = n_snps * world
         kernel_ms = kernel_ms_total / max(1, launches)
-        alg_bytes_per_launch = (n_snps / n_chunks) * (n_samples / 4.0)
+        alg_bytes_per_launch = (n_local / n_chunks) * (n_samples / 4.0)
         achieved = alg_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        kernel_name = table.last_scan_kernel()  # recorded by the dispatch that launched it
         # empirical streaming-read ceiling on the same buffer
         probe_ms = []
         for _ in range(3):
@@ -425,34 +567,36 @@ def main():
                  "continuous_stream": table.get_option(capi.OPT_PIPELINE),
                  "single_mask": table.get_option(capi.OPT_COMPLEMENT),
                  "sub_wave_rows": table.get_option(capi.OPT_SHORT_ROWS)}
-        kernel_name = ("gw::k_scan_cc_sub" if shape["sub_wave_rows"] else
-                       "gw::k_scan_cc_compl" if shape["single_mask"] else
-                       "gw::k_scan_cc_pipe" if shape["continuous_stream"] else "gw::k_scan_cc")
+        traffic, traffic_note = (pmc_traffic(workload, kernel_name) if n_chunks == 1 and world == 1 and not args.snps
+                                 else (None, "PMC figure is per whole-table launch on one GPU"))
         out = {
             "metric": "SNPs/sec case/control chi2 scan",
-            "value": total_snps / (elapsed / args.steps),
+            "value": n_total / (elapsed / args.steps),
             "unit": "SNPs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (strong or world == 1) else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": wl_text, "n_samples": n_samples, "n_snps_per_gpu": n_snps,
-                "n_snps_total": total_snps, "table_GB_per_gpu": geo.device_table_bytes / 1e9,
+                "workload": wl_text, "n_samples": n_samples, "n_snps_per_gpu": n_local,
+                "n_snps_total": n_total, "table_GB_per_gpu": geo.device_table_bytes / 1e9,
                 "algorithmic_bytes_per_snp": n_samples / 4.0,
                 "input": f"restated data/simulate_data.cpp (affy6 MAF spectrum, HWE, coin-flip phenotype), "
                          f"counter-based RNG seed {SEED:#x}, generated in HBM in {t_setup:.2f} s",
-                "sharding": "contiguous SNP ranges, one rank per GPU" if world > 1 else "single GPU",
-                "exchange": f"RCCL {collective['name']} of {RECORD_BYTES} B/SNP to rank 0 in {n_chunks} chunks, "
-                            "overlapped with the scan" if world > 1 else "none",
-                "kernel_shape": shape, "stats_dtype": "f64",
+                "sharding": (f"contiguous SNP ranges of one {n_total}-SNP table, one rank per GPU (rank 0: "
+                             f"[{begin}, {begin + n_local}))" if strong else
+                             "a full-size table per rank" if world > 1 else "single GPU"),
+                "exchange": (f"RCCL {args.collective} of {RECORD_BYTES} B/SNP to rank 0 inside every step, "
+                             f"{n_chunks} piece(s) per step, {n_buf} buffers per piece (gathers run under the "
+                             f"following scans)") if world > 1 else "none",
+                "kernel_shape": shape, "stats_dtype": "f64", "git": git_head(),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.workload),
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_note,
                 "kernel": kernel_name, "kernel_ms": kernel_ms, "launches_timed": launches,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                 "stream_read_probe_GBps": probe_gbps,
@@ -463,13 +607,43 @@ def main():
             out["cpu_baseline"] = cpu_baseline(table, n_samples, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and args.workload == "c3" and not args.snps and not args.no_extra:
-            out["extra_workloads"] = {"c2": side_workload("c2", args.steps, args.warmup),
-                                      "n10k": side_workload("n10k", args.steps, args.warmup)}
+    if rehearse and rank == 0:
+        import numpy as np
+        with gw.GwTable(n_samples, n_total, device=0) as whole:
+            whole.simulate(SEED, 0 if strong else 0, 0)
+            whole.simulate_phenotype(SEED)
+            counts, stats = whole.scan_case_control()
+        ok = True
+        for c in range(n_chunks):
+            cap = bounds[c + 1] - bounds[c]
+            for r in range(world):
+                b0 = shard.snp_range(n_total, r, world)[0] if strong else r * n_job
+                nl = (shard.snp_range(n_total, r, world)[1] - b0) if strong else n_job
+                lo, hi = min(bounds[c], nl), min(bounds[c + 1], nl)
+                raw = rehearsal_last[c][r].numpy()
+                gc = raw[:cap * 32].view(np.uint32).reshape(cap, 8)[:hi - lo]
+                gs = raw[cap * 32:].view(np.float64).reshape(cap, 8)[:hi - lo]
+                if strong:
+                    ok &= bool(np.array_equal(gc, counts[b0 + lo:b0 + hi]) and np.array_equal(gs, stats[b0 + lo:b0 + hi]))
+        out["config"]["rehearsal_gathered_equals_single_scan"] = ok if strong else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     table.close()
+    if out is not None and world == 1 and workload == "c3" and not args.snps:
+        # side measurements, each on its own table after the main one was freed
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"]["c1"] = cpu_baseline_c1()
+        if not args.no_extra:
+            extra = {"c2": side_workload("c2", args.steps, args.warmup),
+                     "n10k": side_workload("n10k", args.steps, args.warmup)}
+            c5 = bench_pairs(args, 0, 1, local_rank, None, steps=3, warmup=1, with_cpu_baseline=False)
+            extra["c5"] = {"workload": c5["config"]["workload"], "ms_per_step": c5["ms_per_step"],
+                           "value": c5["value"], "unit": c5["unit"], "pairs": c5["config"]["pairs"],
+                           "hits_over_30": c5["config"]["hits_over_30"],
+                           "mfma_int8_TOPs": c5["roofline"]["achieved"], "frac": c5["roofline"]["frac"],
+                           "bound": "mfma", "kernel": c5["roofline"]["kernel"], "steps": c5["steps"]}
+            out["extra_workloads"] = extra
     if out is not None:
         print(json.dumps(out))
 

@@ -264,6 +264,11 @@ int gw_timer_stop(gw_table *t, void *hip_stream, float *elapsed_ms);
  * loads (the rows with their padding). */
 int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read);
 int gw_synchronize(gw_table *t);
+/* The kernel instantiation the handle's last case/control scan was dispatched to, spelled the way
+ * rocprofv3's kernel trace prints it (e.g. "gw::k_scan_cc_pipe<2, true, true>"); "" before the first
+ * scan.  bench.py reports it as roofline.kernel and matches it against the stamp of the committed PMC
+ * traffic figure. */
+const char *gw_last_scan_kernel(const gw_table *t);
 
 /* kernel-shape knobs for A/B measurement (defaults are chosen at create) */
 typedef enum gw_option {

@@ -86,7 +86,7 @@ EXPORTS = [
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
     "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected",
-    "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_set_option",
+    "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_last_scan_kernel", "gw_set_option",
     "gw_get_option", "gw_pack_genotype_row", "gw_header_assign", "gw_build_stream_mask", "gw_stream_blocks",
     "gw_block_blocks",
 ]
@@ -133,6 +133,8 @@ def library() -> C.CDLL:
     L.gw_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.gw_stream_read_probe.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.gw_synchronize.argtypes = [vp]
+    L.gw_last_scan_kernel.argtypes = [vp]
+    L.gw_last_scan_kernel.restype = C.c_char_p
     L.gw_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.gw_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     L.gw_pack_genotype_row.argtypes = [vp, vp, C.c_char, C.c_uint32, C.c_int, u16p]
@@ -371,6 +373,9 @@ class GwTable:
 
     def synchronize(self):
         _check(self._L.gw_synchronize(self._h))
+
+    def last_scan_kernel(self) -> str:
+        return self._L.gw_last_scan_kernel(self._h).decode()
 
     def set_option(self, option: int, value: int):
         _check(self._L.gw_set_option(self._h, option, value))

@@ -91,6 +91,7 @@ struct gw_table {
 
     // kernel shape
     int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0;
+    char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
     size_t raw_bytes = 0;
 };
@@ -674,7 +675,8 @@ int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     if (!seg) {
         const gw::ScanShape sh = scan_shape(t);
         GW_HIP(gw::launch_scan_cc(t->tv, t->d_case, t->d_ctrl, t->case_count, t->ctrl_count, snp_begin,
-                                  (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh, stream));
+                                  (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh, stream, nullptr, false,
+                                  t->last_scan_kernel));
         return GW_OK;
     }
     // Column-segmented scan: the masks of a segment fit the LDS, every segment streams its slice of all
@@ -694,7 +696,7 @@ int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
         view.units = std::min(seg, t->tv.units - u0);
         const gw::ScanShape sh = scan_shape(t, view.units);
         GW_HIP(gw::launch_scan_cc(view, t->d_case + u0, t->d_ctrl + u0, t->case_count, t->ctrl_count, snp_begin,
-                                  (uint32_t)n_snps, nullptr, nullptr, sh, stream, t->d_raw, u0 != 0));
+                                  (uint32_t)n_snps, nullptr, nullptr, sh, stream, t->d_raw, u0 != 0, t->last_scan_kernel));
     }
     GW_HIP(gw::launch_finish_raw(t->d_raw, (uint32_t)n_snps, t->case_count, t->ctrl_count, (uint32_t *)d_counts,
                                  (double *)d_stats, stream));
@@ -1070,6 +1072,8 @@ int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
     if (bytes_read) *bytes_read = t->tv.n_snps * t->tv.row_stride_u * 16ull;
     return GW_OK;
 }
+
+const char *gw_last_scan_kernel(const gw_table *t) { return t ? t->last_scan_kernel : ""; }
 
 int gw_synchronize(gw_table *t) {
     if (!t) return fail(GW_E_INVALID, "NULL table");

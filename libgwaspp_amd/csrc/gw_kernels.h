@@ -47,7 +47,10 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
                           // column-segmented scan: tv / masks describe one segment of the columns and the six
                           // sums per row go to d_raw[row][6] (added to it when raw_accumulate) -- not with
                           // shape.complement or shape.short_rows
-                          uint32_t *d_raw = nullptr, bool raw_accumulate = false);
+                          uint32_t *d_raw = nullptr, bool raw_accumulate = false,
+                          // char[96] or null: receives the kernel instantiation the launch went to, spelled as
+                          // rocprofv3 prints it (e.g. "gw::k_scan_cc_pipe<2, true, true>")
+                          char *kernel_name = nullptr);
 // ... and its last step: counts[n][8] and stats[n][8] from the accumulated sums
 hipError_t launch_finish_raw(const uint32_t *d_raw, uint32_t n_rows, uint32_t case_count, uint32_t ctrl_count,
                              uint32_t *d_counts, double *d_stats, hipStream_t stream);

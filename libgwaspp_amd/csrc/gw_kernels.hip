@@ -24,6 +24,9 @@
 // (the all-pairs BOOST path is in gw_boost*.hip)
 #include "gw_kernels.h"
 
+#include <cstdarg>
+#include <cstdio>
+
 namespace gw {
 
 // ---------------------------------------------------------------------------
@@ -619,6 +622,17 @@ __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
+// the instantiation a scan launch went to, as rocprofv3 prints it (launch_scan_cc's kernel_name)
+static thread_local char *t_name_out = nullptr;
+static void note_kernel(const char *fmt, ...) {
+    if (!t_name_out) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_name_out, 96, fmt, ap);
+    va_end(ap);
+}
+static const char *tf(bool b) { return b ? "true" : "false"; }
+
 template <int G, int STEPS, bool PACK>
 static hipError_t launch_scan_sub_p(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
     int grid = sh.grid_blocks;
@@ -631,6 +645,7 @@ static hipError_t launch_scan_sub_p(const ScanArgs &args, const ScanShape &sh, h
         }
         grid = sh.compute_units * resident;
     }
+    note_kernel("gw::k_scan_cc_sub<%d, %d, %s>", G, STEPS, tf(PACK));
     hipLaunchKernelGGL((k_scan_cc_sub<G, STEPS, PACK>), dim3(grid), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
@@ -641,12 +656,15 @@ static hipError_t launch_scan_sub(const ScanArgs &args, const ScanShape &sh, boo
 
 template <int UNROLL, bool MASK_LDS, bool NT>
 static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
-    if (sh.pipeline && UNROLL <= 4)
+    if (sh.pipeline && UNROLL <= 4) {
+        note_kernel("gw::k_scan_cc_pipe<%d, %s, %s>", UNROLL <= 4 ? UNROLL : 4, tf(MASK_LDS), tf(NT));
         hipLaunchKernelGGL((k_scan_cc_pipe<(UNROLL <= 4 ? UNROLL : 4), MASK_LDS, NT>), dim3(sh.grid_blocks),
                            dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
-    else
+    } else {
+        note_kernel("gw::k_scan_cc<%d, %s, %s>", UNROLL, tf(MASK_LDS), tf(NT));
         hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
                            dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
+    }
     return hipGetLastError();
 }
 
@@ -687,8 +705,13 @@ hipError_t launch_finish_raw(const uint32_t *d_raw, uint32_t n_rows, uint32_t ca
 hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 *d_ctrl,
                           uint32_t case_count, uint32_t ctrl_count, uint64_t row_begin,
                           uint32_t n_rows, uint32_t *d_counts, double *d_stats,
-                          const ScanShape &sh, hipStream_t stream, uint32_t *d_raw, bool raw_accumulate) {
+                          const ScanShape &sh, hipStream_t stream, uint32_t *d_raw, bool raw_accumulate,
+                          char *kernel_name) {
     if (n_rows == 0) return hipSuccess;
+    struct NameScope {  // note_kernel() writes here for the duration of this call
+        explicit NameScope(char *p) { t_name_out = p; }
+        ~NameScope() { t_name_out = nullptr; }
+    } name_scope(kernel_name);
     ScanArgs a;
     a.table = tv.base;
     a.row_stride_u = tv.row_stride_u;
@@ -725,6 +748,7 @@ hipError_t launch_scan_cc(const TableView &tv, const u32x4 *d_case, const u32x4 
         }
     }
     if (sh.complement) {
+        note_kernel("gw::k_scan_cc_compl<%d>", (sh.unroll == 1 || sh.unroll == 4 || sh.unroll == 8) ? sh.unroll : 2);
         switch (sh.unroll) {
         case 1: hipLaunchKernelGGL((k_scan_cc_compl<1>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;
         case 4: hipLaunchKernelGGL((k_scan_cc_compl<4>), dim3(sh.grid_blocks), dim3(sh.block_threads), sh.lds_bytes, stream, a); break;

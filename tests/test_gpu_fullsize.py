@@ -116,3 +116,74 @@ def test_million_sample_rows_use_the_single_mask_kernel(oracle):
             ca, co = oracle.stream_cc_dist(row[0], g, cs, ct, nc, nt)
             assert tuple(int(v) for v in counts[r]) == ca + co
             np.testing.assert_allclose(stats[r], oracle.assoc_stats(ca, co), rtol=1e-10, atol=1e-12)
+
+
+def test_config5_all_pairs_of_100k_snps(oracle):
+    """BASELINE.json configs[4] at full size on one GPU: the BOOST / KSA pre-screen of computeBoost
+    (algorithms/epistasis_func.cpp:393-486 over the margin-assisted tables of table5.cpp:989-1150) over all
+    4 999 950 000 pairs of 100 000 SNPs x 10 000 samples, three ways -- int8-MFMA kernels with the
+    single-precision pre-filter (the default), the same with every pair's FP64 measure, and the vector-ALU
+    kernels -- which must list the same pairs with the same measures; the oracle's measure on eight
+    sampled 32 x 32 blocks of the pair space and on 50 of the listed pairs."""
+    if gw.device_count() == 0:
+        pytest.fail("no HIP device visible")
+    n, m, thr = 10_000, 100_000, 30.0
+    order = ["snp_a", "snp_b"]
+    with gw.GwTable(n, m) as t:
+        t.simulate(SEED, 0, 0)
+        t.simulate_phenotype(SEED)
+        cs, ct, nc, nt = t.get_case_control()
+        gs = oracle.geometry_stream(n)
+        lists = {}
+        for name, mfma, pre in (("mfma+prefilter", 1, 1), ("mfma", 1, 0), ("valu+prefilter", 0, 1)):
+            t.set_option(capi.OPT_BOOST_MATRIX_CORES, mfma)
+            t.set_option(capi.OPT_BOOST_PREFILTER, pre)
+            hits, n_hits, n_pairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=thr, max_hits=1 << 18,
+                                                               extremes=False)
+            assert n_pairs == m * (m - 1) // 2 == 4_999_950_000          # 64-bit pair tally
+            assert n_hits == len(hits) and 1000 < n_hits < (1 << 18)
+            assert np.all(hits["snp_a"] < hits["snp_b"]) and np.all(hits["measure"] > thr)
+            lists[name] = np.sort(hits, order=order)
+        ref = lists["mfma+prefilter"]
+        for name in ("mfma", "valu+prefilter"):
+            assert np.array_equal(lists[name], ref), name                # same pairs, bit-identical measures
+        assert len(np.unique(ref[order])) == len(ref)                    # no pair listed twice
+        t.set_option(capi.OPT_BOOST_MATRIX_CORES, 1)
+        t.set_option(capi.OPT_BOOST_PREFILTER, 1)
+
+        # the oracle on sampled blocks: 8 x (32 x 32) = 8192 pairs, anywhere in the triangle
+        rng = np.random.default_rng(5)
+        listed = {(int(h["snp_a"]), int(h["snp_b"])): float(h["measure"]) for h in ref}
+        checked = 0
+        for _ in range(8):
+            a0 = int(rng.integers(0, m - 64))
+            b0 = int(rng.integers(a0 + 32, m - 32))
+            got = t.boost_measures(a0, 32, b0, 32)
+            rows = np.concatenate([t.download_rows(a0, 32), t.download_rows(b0, 32)])
+            flat = oracle.boost_all_pairs(rows, gs, cs, ct, nc, nt)
+            k = 0
+            for i in range(64):
+                for j in range(i + 1, 64):
+                    if i < 32 <= j:
+                        w, g = flat[k], got[i, j - 32]
+                        assert (np.isnan(w) and np.isnan(g)) or abs(g - w) <= 1e-10 * abs(w) + 1e-8
+                        if not np.isnan(w):
+                            # the screen's verdict on this pair is the oracle's
+                            assert ((a0 + i, b0 + j - 32) in listed) == (g > thr)
+                        checked += 1
+                    k += 1
+        assert checked == 8 * 32 * 32
+
+        # ... and on 50 of the listed pairs, from the pair's own rows
+        pad = gs.words * 64
+        for h in ref[rng.choice(len(ref), size=50, replace=False)]:
+            ra, rb = t.download_rows(int(h["snp_a"]), 1)[0], t.download_rows(int(h["snp_b"]), 1)[0]
+            mar = []
+            for row in (ra, rb):
+                ca, co = oracle.stream_cc_dist(row, gs, cs, ct, nc, nt)
+                mar.append(oracle.marginal_information(ca, co, nc + nt))
+            c16, t16 = oracle.stream_cc_contingency(ra, rb, gs, cs, ct)
+            c16[15] -= pad - nc          # exact tables (table5.cpp:1031,1062): members missing at both markers
+            t16[15] -= pad - nt
+            want = oracle.boost_measure(c16, t16, mar[0], mar[1], nc + nt)
+            assert want > thr and abs(h["measure"] - want) <= 1e-10 * abs(want) + 1e-8

@@ -60,7 +60,10 @@ def test_all_pairs_kernels_count_what_the_text_holds(oracle, name):
     cls = [row_classes(ln) for ln in lines]
     cases, ctrls = read_tfam_status(name)
     if len(cases) == 0 or len(ctrls) == 0:
-        pytest.skip("one group is empty in this set")
+        # the 'plain' sets (25 % missing calls) put everybody in one group: split them by sample index so that
+        # the nine-cell kernels (tables WITH missing calls) are pinned to the text too
+        cases = np.arange(0, n, 2, dtype=np.int32)
+        ctrls = np.arange(1, n, 2, dtype=np.int32)
     cs, nc = gw.build_stream_mask(cases, n)
     ct, nt = gw.build_stream_mask(ctrls, n)
     mar = []

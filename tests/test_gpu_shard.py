@@ -1,0 +1,146 @@
+"""The N > 1 path with REAL HIP scans: two ranks, both on device 0 (the GPU box has one GPU;
+RCCL refuses two ranks on one device, so the process group is gloo and the records cross through host
+memory), each rank generates and scans its own contiguous SNP shard of ONE table with the HIP kernel, the
+96-byte records are gathered to rank 0 with the same shard.* helpers bench.py uses, and rank 0's result is
+compared byte for byte with a single-process scan of the whole table.  Needs a real MI355X: pytest -m gpu."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import libgwaspp_amd as gw
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORD = 96
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if gw.device_count() == 0:
+        pytest.fail("no HIP device visible: the gpu tests must run on the GPU box")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, n, seed, missing, n_chunks, q):
+    sys.path.insert(0, ROOT)
+    import torch                      # before the first call into libgwscan.so (see capi.py)
+    import torch.distributed as dist
+    import libgwaspp_amd as gw
+    from libgwaspp_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        begin, end = shard.snp_range(total, rank, world)
+        n_local = end - begin
+        cap = max(shard.snp_range(total, r, world)[1] - shard.snp_range(total, r, world)[0] for r in range(world))
+        bounds = shard.chunk_bounds(cap, n_chunks)
+        stream = torch.cuda.Stream()
+        gathered = []
+        with gw.GwTable(n, n_local, device=0) as t:
+            t.simulate(seed, begin, missing)           # global SNP index = shard begin + row
+            t.simulate_phenotype(seed)
+            kernel = None
+            for c in range(len(bounds) - 1):
+                rows_cap = bounds[c + 1] - bounds[c]
+                lo, hi = min(bounds[c], n_local), min(bounds[c + 1], n_local)
+                buf = torch.zeros(rows_cap * RECORD, dtype=torch.uint8, device="cuda")
+                base = buf.data_ptr()
+                if hi > lo:
+                    t.scan_case_control_device(lo, hi - lo, base, base + rows_cap * 32, stream.cuda_stream)
+                    kernel = t.last_scan_kernel()
+                stream.synchronize()
+                out, work = shard.gather_records(dist, buf.cpu(), rank, world, dst=0, async_op=True)
+                gathered.append((out, work))
+            for _, w in gathered:
+                w.wait()
+        if rank == 0:
+            q.put(([[x.numpy() for x in out] for out, _ in gathered], bounds, kernel))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,total,missing,n_chunks", [(10_000, 20_001, 655, 1), (100_000, 3_001, 0, 2),
+                                                       (500_000, 1_501, 0, 2)])
+def test_two_ranks_scan_their_shards_on_the_gpu_and_gather(n, total, missing, n_chunks):
+    import torch.multiprocessing as mp
+    from libgwaspp_amd import shard
+    world, seed = 2, 0x5EED
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, missing, n_chunks, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        chunks, bounds, kernel = q.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+    assert all(p.exitcode == 0 for p in procs)
+    assert kernel.startswith("gw::k_scan_cc")
+    # the single-process scan of the whole table
+    with gw.GwTable(n, total) as t:
+        t.simulate(seed, 0, missing)
+        t.simulate_phenotype(seed)
+        counts, stats = t.scan_case_control()
+    seen = 0
+    for r in range(world):
+        b, e = shard.snp_range(total, r, world)
+        for c in range(len(bounds) - 1):
+            cap = bounds[c + 1] - bounds[c]
+            lo, hi = min(bounds[c], e - b), min(bounds[c + 1], e - b)
+            raw = chunks[c][r]
+            got_c = raw[:cap * 32].view(np.uint32).reshape(cap, 8)[:hi - lo]
+            got_s = raw[cap * 32:].view(np.float64).reshape(cap, 8)[:hi - lo]
+            assert np.array_equal(got_c, counts[b + lo:b + hi])
+            assert np.array_equal(got_s, stats[b + lo:b + hi])     # same kernel, same rows: bit-identical
+            seen += hi - lo
+    assert seen == total
+
+
+def _torchrun(extra, nproc=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly_before_any_gpu_call():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has a GPU per rank")
+    r = _torchrun(["--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "has no GPU of its own" in r.stderr and "nothing was launched" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_multi_rank_logic_rehearsed_on_one_gpu():
+    """bench.py's own N = 2 step loop (config 4 sharding, ragged shards, two pieces per step, three record
+    buffers per piece) with both ranks on device 0 and a gloo gather: rank 0 checks the gathered records of the
+    last step against one scan of the whole table."""
+    r = _torchrun(["--rehearse-on-one-gpu", "--snps", "40001", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["n_snps_total"] == 40001 and line["config"]["n_snps_per_gpu"] == 20001
+    assert line["config"]["workload"].startswith("REHEARSAL ON ONE GPU")
+    assert line["config"]["rehearsal_gathered_equals_single_scan"] is True
+    assert line["roofline"]["kernel"].startswith("gw::k_scan_cc_pipe")
