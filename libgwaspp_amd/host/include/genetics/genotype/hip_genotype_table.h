@@ -36,33 +36,33 @@ public:
     virtual ~HipGenotypeTable();
 
     // ---- ingest (geno_table.h:51-53)
-    void addGenotype(int rIdx, int cIdx, const std::string &gt);
-    void addGenotypeRow(int rIdx, std::string::const_iterator &it, std::string::const_iterator &it_end, char delim);
-    void addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim);
+    void addGenotype(int rIdx, int cIdx, const std::string &gt) override;
+    void addGenotypeRow(int rIdx, std::string::const_iterator &it, std::string::const_iterator &it_end, char delim) override;
+    void addGenotypeRow(int rIdx, const char *p_begin, const char *p_end, char delim) override;
 
-    ushort encodeGenotype(const std::string &gt);
-    const char *decodeGenotype(ushort encoded_gt);
-    bool isGenotypeHomozygous(ushort encoded_gt);
-    DataBlock operator()(int r, int c);
+    ushort encodeGenotype(const std::string &gt) override;
+    const char *decodeGenotype(ushort encoded_gt) override;
+    bool isGenotypeHomozygous(ushort encoded_gt) override;
+    DataBlock operator()(int r, int c) override;
 
     // ---- single marker (single_marker_analyzable.h:132-145)
-    void selectMarker(uint rIdx);
-    void getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist);
-    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs, CaseControlGenotypeDistribution &ccgd);
-    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd);
-    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd, marginal_information &m);
+    void selectMarker(uint rIdx) override;
+    void getGenotypeDistribution(uint rIdx, GenotypeDistribution &dist) override;
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs, CaseControlGenotypeDistribution &ccgd) override;
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd) override;
+    void getCaseControlGenotypeDistribution(uint rIdx, CaseControlGenotypeDistribution &ccgd, marginal_information &m) override;
 
     // ---- pairs (pairwise_marker_analyzable.h:175-187)
-    void selectMarkerPair(uint rIdx1, uint rIdx2);
-    void getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct);
-    void getContingencyTable(uint rIdx1, uint rIdx2, ushort *column_set, ContingencyTable &ct);
-    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs, CaseControlContingencyTable &ccct);
-    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlContingencyTable &ccct);
+    void selectMarkerPair(uint rIdx1, uint rIdx2) override;
+    void getContingencyTable(uint rIdx1, uint rIdx2, ContingencyTable &ct) override;
+    void getContingencyTable(uint rIdx1, uint rIdx2, ushort *column_set, ContingencyTable &ct) override;
+    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs, CaseControlContingencyTable &ccct) override;
+    void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlContingencyTable &ccct) override;
     void getCaseControlContingencyTable(uint rIdx1, uint rIdx2, const marginal_information &m1,
-                                        const marginal_information &m2, CaseControlContingencyTable &ccct);
+                                        const marginal_information &m2, CaseControlContingencyTable &ccct) override;
 
     // ---- mask (case_control_selectable.h:42)
-    void selectCaseControl(CaseControlSet &ccs);
+    void selectCaseControl(CaseControlSet &ccs) override;
 
     // ---- batch extensions (what the per-row getters are served from)
     // addGenotypeRow for rows rBegin, rBegin+1, ...: packed by all host cores, one upload
@@ -88,7 +88,7 @@ public:
     gw_table *handle() { settle(); return tbl; }
 
 protected:
-    void initialize();
+    void initialize() override;
     void invalidate();
     void install(CaseControlSet &ccs);
     void fill_dist_cache(uint rIdx);

@@ -508,3 +508,31 @@ def test_column_segmented_scan(oracle, n, m, seg):
             t.set_option(capi.OPT_PIPELINE, pipe)
             c3, s3 = t.scan_case_control()
             assert np.array_equal(c3, counts) and np.array_equal(s3, stats), (unroll, threads, pipe)
+
+
+# --------------------------------------------------------------------------
+# masks made by the REAL reference CaseControlSet (oracle/_ref, compiled from the reference's own
+# case_control_set.cpp + index_set.cpp in the build container; the .so travels to the GPU box)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m", [(70, 20), (1000, 64), (4097, 33), (10_000, 200)])
+def test_scan_with_masks_from_the_real_reference_object(oracle, n, m):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libref_ccs.so did not travel with this snapshot")
+    rng = np.random.default_rng(3 * n + m)
+    codes = _random_codes(rng, m, n, p_missing=0.03)
+    ts = oracle.pack_codes(codes, "stream")
+    gs = oracle.geometry_stream(n)
+    status = rng.integers(0, 3, size=n)          # 0 control, 1 case, 2 neither
+    cases = np.flatnonzero(status == 1).astype(np.int32)
+    ctrls = np.flatnonzero(status == 0).astype(np.int32)
+    _, _, sc, st, cnt = oracle.ref_ccs(n, cases, ctrls)   # stream_case_begin() / stream_control_begin() bytes
+    nc, nt = int(cnt[0]), int(cnt[1])
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(sc, st, nc, nt)
+        counts, stats = t.scan_case_control()
+    # expected counts straight from the code array (not from the oracle's masks)
+    for r in range(m):
+        want = tuple(int((codes[r][grp] == c).sum()) for grp in (cases, ctrls) for c in (1, 2, 3, 0))
+        assert tuple(int(v) for v in counts[r]) == want
+        _assert_stats(stats[r], oracle.assoc_stats(want[:4], want[4:]))
