@@ -232,8 +232,8 @@ int gw_pair_case_control_contingency(gw_table *t, const uint32_t *pairs, uint64_
  * *n_hits is the total found (may exceed max_hits), *n_pairs the pairs
  * evaluated, *max_measure / *min_measure the extremes (:472-480; the
  * reference tracks but never prints them).  Any of the four may be NULL; with
- * both extremes NULL the screen may skip the FP64 measure of pairs that a
- * single-precision bound proves to be below the threshold
+ * both extremes NULL the screen skips the FP64 measure of pairs that a
+ * single-precision bound plus its error bound proves to be below the threshold
  * (GW_OPT_BOOST_PREFILTER) -- same hit list, ~1.5x faster at N = 10 k. */
 typedef struct gw_boost_hit {
     uint32_t snp_a, snp_b;
@@ -281,11 +281,17 @@ typedef enum gw_option {
                                 can stage one mask in LDS and take controls = all - cases: 0 never,
                                 1 (default) only where two masks do not fit the LDS (650 k < N <= 1.3 M),
                                 2 whenever possible; get returns whether the current masks/shape use it */
-    GW_OPT_BOOST_PREFILTER = 8, /* gw_boost_screen without max_measure / min_measure: 1 (default) decide each
-                                pair first by a single-precision bound of the measure and evaluate the FP64
-                                measure only where bound >= threshold - slack (slack = 2n * 1e-4 + 0.05;
-                                the hit list is the same, listed measures are the FP64 ones); 0 never;
-                                2 diagnostic: gw_boost_measures returns the bound instead of the measure */
+    GW_OPT_BOOST_PREFILTER = 8, /* gw_boost_screen without max_measure / min_measure: 1 (default) evaluate a
+                                single-precision bound of each pair's measure first, together with a running
+                                error bound err with |bound - measure| <= err (derived in
+                                libgwaspp_amd/csrc/gw_boost_dev.h: ~6e-8 * (145 n + 30 |s| + ...), 0.09 at
+                                n = 10 k), and run the FP64 measure only where bound + err >= threshold -- the hit
+                                list and its FP64 measures are those of the all-FP64 screen; 0 never;
+                                2 / 3 diagnostic: gw_boost_measures returns the bound / its error bound */
+    GW_OPT_BOOST_PREFILTER_TRIPS = 12, /* get: how many pre-filtered screens of this handle found a pair whose FP64
+                                measure lay outside [bound - err, bound + err] (the error model's assumptions on
+                                v_log_f32 / v_rcp_f32 failing) and were therefore repeated with every pair in
+                                FP64; set 1: treat every screen as such (test hook), 0: normal */
     GW_OPT_BOOST_MATRIX_CORES = 9, /* pair tables as int8 MFMA dot products of class vectors (1, default: four
                                 products per pair when no call of the table is missing, nine otherwise)
                                 or AND + popcount on the vector ALU (0); 2 = as 1 but always the kernels

@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libgwscan.so")
+# GW_LIBGWSCAN: an alternative build of the same library (kernel experiments, tools/build_variant.sh)
+_LIB = os.environ.get("GW_LIBGWSCAN") or os.path.join(_HERE, "libgwscan.so")
 
 LAYOUT_STREAM = 5
 LAYOUT_BLOCK = 3
@@ -28,6 +29,7 @@ OPT_BOOST_PREFILTER = 8
 OPT_BOOST_MATRIX_CORES = 9
 OPT_SHORT_ROWS = 10
 OPT_COLUMN_SEGMENT = 11
+OPT_BOOST_PREFILTER_TRIPS = 12
 
 
 class GwError(RuntimeError):

@@ -307,16 +307,18 @@ __global__ void __launch_bounds__(256) k_boost(BoostArgs a) {
                     }
                 }
                 ++n_eval;
+                float bound = 0.0f, err = 0.0f;
                 if (PRE) {
-                    const float bound = boost_bound(ca, co, a.marf[i], a.marf[j], (float)a.n_individs,
-                                                    1.0f / (float)a.n_individs);
-                    if (a.dense) {  // diagnostic form: the bound itself
-                        a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
+                    bound = boost_bound(ca, co, a.marf[i], a.marf[j], (float)a.n_individs,
+                                        1.0f / (float)a.n_individs, err);
+                    if (a.dense) {  // diagnostic form: the bound itself, or its error bound
+                        a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)(a.dense_err ? err : bound);
                         continue;
                     }
-                    if (bound < a.bound_threshold) continue;  // false for NaN
+                    if (bound_rules_out(bound, err, a.bound_threshold)) continue;
                 }
                 measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+                if (PRE) check_bound(measure, bound, err, a.tally);
                 if (!PRE) {
                     vmax = fmax(vmax, measure);
                     vmin = fmin(vmin, measure);
@@ -401,14 +403,14 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct, bool both_groups) {
+                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
     a.a_begin = a_begin; a.n_a = n_a; a.b_begin = b_begin; a.n_b = n_b;
     a.n_individs = (int)n_individs; a.threshold = threshold;
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
-    a.marf = d_marf; a.bound_threshold = bound_threshold;
+    a.marf = d_marf; a.bound_threshold = bound_threshold; a.dense_err = dense_err ? 1 : 0;
     a.cct = d_cct;
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16

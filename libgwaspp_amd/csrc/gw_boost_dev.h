@@ -59,11 +59,34 @@ __device__ __forceinline__ double boost_measure(const uint32_t (&ca)[9], const u
 // The same quantity in single precision, arranged for one v_log_f32 per cell and group:
 //   measure = 2 * sum_cells [ x ln(r_case) + y ln(r_ctrl) ] + 2 n ln(tao),
 //   r = (k/n) / (pab * pbc * pca) = k / (x+y) / n * qb[b] * qa[a]
-// Its error against the FP64 measure stays far below the slack the caller subtracts from the
-// threshold (tests/test_gpu_boost.py measures it), so "bound < threshold - slack" proves that the
-// pair cannot pass; anything else (including NaN) is decided by the FP64 measure.
+// together with a RUNNING ERROR BOUND `err` (Higham-style, first order in u = 2^-24, constants rounded up):
+// |bound - measure| <= err for every pair, so "bound + err < threshold" PROVES that the pair cannot pass and
+// anything else (including NaN / Inf) is decided by the FP64 measure.  Derivation, per operation:
+//   * float(k), float(x+y) exact (counts < 2^24); every mul / add / float(double) rounds within u;
+//     v_rcp_f32 within 2u (1 ulp); v_log_f32 within 2u |log2 z| + 4u (1 ulp, plus an absolute allowance of
+//     2^-22 around z = 1) -- the two hardware assumptions; the screen verifies them at run time (below);
+//   * argument of a cell's log: rcp 2u, inv_n u, rcp*inv_n u, qb u, qa u, qb*qa u, k*rs u, (.)*(qb qa) u = 9u
+//     -> log2 off by 9u/ln2 = 13.2u, hardware log 2.01u |l| + 4.01u, product k*l u:
+//     |t - k log2 z| <= 17.3u k + 3.02u |t|;  summing the 18 terms recursively adds 17.1u T, T = sum |t|:
+//     |s - S| <= 17.3u n + 20.2u T                      (sum of all k <= n)
+//   * tao: rb u, pa u, rb*pa u, sum of two u, *(x+y) u, eight more adds of non-negative terms: 13.1u relative
+//     -> log2 off by 18.95u, hardware log 2.01u |L| + 4.01u, n*L u:  |nL - n log2 tao| <= 23u n + 3.02u n |L|
+//   * s + nL, the factor 2 ln 2 (itself rounded) and the product: 3.1u |bound|
+//   => |bound - measure| <= 2 ln 2 * u * (40.3 n + 20.2 T + 3.02 n |L|) + 3.1u |bound|
+//   * T needs no per-term work: with S- the sum of the negative terms, T = S + 2 S-, and ln z >= 1 - 1/z gives
+//     k ln z_k >= k - e_k with e_k = k / z_k = n * (the cell's share of tao), so S- <= sum e_k / ln 2 = n tao / ln 2:
+//     T <= |s| + 2.886 n tao
+//   => |bound - measure| <= u * (55.9 n + 28.1 |s| + 81 n tao + 4.19 n |L| + 3.1 |bound|);
+//   err below uses (58, 30, 87, 4.5, 6): room for the second-order terms, its own float evaluation and the
+//   rounding of bound + err.
+// At n = 10 000 (tao ~ 1) that is ~0.09 -- twenty times below the empirical slack (2n * 1e-4 + 0.05) it replaces;
+// measured |bound - measure| / err stays below 0.1 (tests/test_gpu_boost.py prints it).
+// Run-time check of the assumptions: every pair that does get its FP64 measure is compared with its bound, and
+// a pair with |measure - bound| > err bumps tally[2]; the host then repeats the call with every pair in FP64
+// (gw_capi.cpp boost_common; GW_OPT_BOOST_PREFILTER_TRIPS counts such calls -- none has been seen).
 __device__ __forceinline__ float boost_bound(const uint32_t (&ca)[9], const uint32_t (&co)[9],
-                                             const SnpMarginF &f1, const SnpMarginF &f2, float n, float inv_n) {
+                                             const SnpMarginF &f1, const SnpMarginF &f2, float n, float inv_n,
+                                             float &err) {
     float s = 0.0f, tao = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -79,7 +102,18 @@ __device__ __forceinline__ float boost_bound(const uint32_t (&ca)[9], const uint
             s += y ? ly : 0.0f;
         }
     }
-    return 1.3862943611198906f * (s + n * __log2f(tao));  // 2 ln 2
+    const float lt = __log2f(tao);
+    const float r = 1.3862943611198906f * (s + n * lt);  // 2 ln 2
+    err = 5.9604645e-8f * (n * (58.0f + 87.0f * tao + 4.5f * fabsf(lt)) + 30.0f * fabsf(s) + 6.0f * fabsf(r));
+    return r;
+}
+// true: the pair is provably below the threshold (NaN / Inf anywhere -> false -> FP64 decides)
+__device__ __forceinline__ bool bound_rules_out(float bound, float err, float bound_threshold) {
+    return bound + err < bound_threshold;
+}
+// the run-time check of the error model, for a pair that has both values
+__device__ __forceinline__ void check_bound(double measure, float bound, float err, unsigned long long *tally) {
+    if (fabs(measure - (double)bound) > (double)err) atomicAdd(&tally[2], 1ull);  // false for NaN
 }
 
 struct BoostArgs {
@@ -93,11 +127,12 @@ struct BoostArgs {
     double threshold;
     BoostHit *hits;
     unsigned long long max_hits;
-    unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
+    unsigned long long *tally;  // [0] hits, [1] pairs evaluated, [2] ordered max (PRE: pairs outside the bound's error model), [3] ordered min
     double *dense;              // n_a x n_b, or null
+    int dense_err;              // PRE + dense (diagnostic): 0 = write the bound, 1 = write its error bound
     const SnpMarginF *marf;     // PRE only
     const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
-    float bound_threshold;      // PRE: pairs whose FP32 bound is below this are not hits
+    float bound_threshold;      // PRE: the threshold rounded down to float; bound + err < this rules a pair out
 };
 
 

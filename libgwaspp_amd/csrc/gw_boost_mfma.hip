@@ -180,9 +180,10 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) c4[g][k] = (uint32_t)acc[g][k][r] >> 6;  // every product was 64
                 tables(c4, f1, f1 + 3, ca, co);
-                const float bound = boost_bound(ca, co, mf1, mf2, nf, inv_n);
-                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)bound;
-                else if (!(bound < a.bound_threshold)) need |= 1u << r;
+                float err;
+                const float bound = boost_bound(ca, co, mf1, mf2, nf, inv_n, err);
+                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)(a.dense_err ? err : bound);
+                else if (!bound_rules_out(bound, err, a.bound_threshold)) need |= 1u << r;
             } else {
                 need |= 1u << r;
             }
@@ -211,6 +212,10 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
         if (!PRE) {
             vmax = fmax(vmax, measure);
             vmin = fmin(vmin, measure);
+        } else if (!a.dense) {  // few pairs get here: the bound again, checked against the measure
+            float err;
+            const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n, err);
+            check_bound(measure, bound, err, a.tally);
         }
         if (measure > a.threshold) {  // :482-484
             const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);

@@ -81,6 +81,7 @@ struct gw_table {
     gw::u32x4 *d_cct = nullptr;  // block-tiled copy of d_cc for the MFMA pair kernel (tables without missing calls)
     double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
+    uint64_t prefilter_trips = 0;  // screens repeated in FP64 because a pair fell outside the bound's error model
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
     unsigned long long *d_tally = nullptr;
 
@@ -90,7 +91,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0;
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
     size_t raw_bytes = 0;
@@ -921,26 +922,36 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         e = hipMalloc((void **)&d_dense, n_a * n_b * sizeof(double));
         if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0xFF, n_a * n_b * sizeof(double), t->stream);  // NaN
     }
-    // FP32 bound first where nobody asked for the extremes: a pair is dropped without its FP64 measure
-    // only if bound < threshold - slack, slack = 2n * 1e-4 + 0.05 (the bound's error grows with n; see
-    // boost_bound and tests/test_gpu_boost.py, which measures it).  Option 2 = diagnostic: the dense
-    // form returns the bound instead of the measure.
-    const bool diag = dense && t->opt_prefilter == 2;
+    // FP32 bound first where nobody asked for the extremes: a pair is dropped without its FP64 measure only if
+    // bound + err < threshold, err = the bound's own running error bound (gw_boost_dev.h boost_bound).
+    // Options 2 / 3 = diagnostic: the dense form returns the bound / its error bound instead of the measure.
+    const bool diag = dense && t->opt_prefilter >= 2;
     const bool pre = diag || (!dense && !vmax && !vmin && t->opt_prefilter != 0);
     float bound_thr = 0.0f;
     if (pre && !diag) {
-        const double cut = threshold - (2.0 * (double)t->sel_individs * 1.0e-4 + 0.05);
-        bound_thr = (float)cut;
-        if (!((double)bound_thr <= cut)) bound_thr = std::nextafter(bound_thr, -INFINITY);  // round down; NaN stays NaN
+        bound_thr = (float)threshold;
+        if (!((double)bound_thr <= threshold)) bound_thr = std::nextafter(bound_thr, -INFINITY);  // round down; NaN stays NaN
     }
-    if (e == hipSuccess)
-        e = gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin, (uint32_t)n_a,
-                             (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits,
-                             max_hits, t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, pre, bound_thr,
-                             t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2);
+    auto launch = [&](bool prefilter) {
+        return gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
+                                (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, max_hits,
+                                t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
+                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3);
+    };
+    if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
     if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess && pre && !diag && (tally[2] != 0 || t->opt_prefilter_selftest)) {
+        // a pair whose FP64 measure lies further from its bound than the bound's error model allows: the model's
+        // hardware assumptions do not hold here, so nothing the bound ruled out can be trusted -- the whole block
+        // again with every pair in FP64 (never seen on gfx950; GW_OPT_BOOST_PREFILTER_TRIPS counts it)
+        ++t->prefilter_trips;
+        e = hipMemcpyAsync(t->d_tally, init, sizeof init, hipMemcpyHostToDevice, t->stream);
+        if (e == hipSuccess) e = launch(false);
+        if (e == hipSuccess) e = hipMemcpyAsync(tally, t->d_tally, sizeof tally, hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    }
     if (e == hipSuccess && hits && max_hits) {
         const uint64_t n = std::min<uint64_t>(tally[0], max_hits);
         if (n) e = hipMemcpy(hits, d_hits, n * sizeof(gw::BoostHit), hipMemcpyDeviceToHost);
@@ -1127,8 +1138,11 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_segment = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
-        if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 (diagnostic)");
+        if (v < 0 || v > 3) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default), 2 or 3 (diagnostic)");
         t->opt_prefilter = (int)v;
+        return GW_OK;
+    case GW_OPT_BOOST_PREFILTER_TRIPS:  // set: 1 = treat every pre-filtered screen as tripped (exercises the FP64 repeat), 0 = normal
+        t->opt_prefilter_selftest = v ? 1 : 0;
         return GW_OK;
     default:
         return fail(GW_E_INVALID, "unknown option %d", option);
@@ -1147,6 +1161,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_PIPELINE: *v = sh.pipeline; return GW_OK;
     case GW_OPT_COMPLEMENT: *v = sh.complement; return GW_OK;
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
+    case GW_OPT_BOOST_PREFILTER_TRIPS: *v = (int64_t)t->prefilter_trips; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

@@ -129,14 +129,18 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream,
-                        // FP32 bound first (prefilter), the FP64 measure only where it cannot rule a pair out;
-                        // no extremes in d_tally then; with d_dense the bound itself is written (diagnostic)
+                        // FP32 bound first (prefilter), the FP64 measure only for pairs that bound + error bound
+                        // cannot prove to be below `bound_threshold` (the threshold rounded down to float); no
+                        // extremes in d_tally then, d_tally[2] counts evaluated pairs that fall outside the bound's
+                        // error model instead; with d_dense the bound itself is written (diagnostic)
                         const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f,
                         // tables without a missing call: corners as int8 MFMA dot products (k_boost_mfma)
                         // over the block-tiled copy of the compacted rows (launch_retile_cc), or null
                         const u32x4 *d_cct = nullptr,
                         // force the kernels that keep both groups' accumulators (what case groups >= 65 536 get)
-                        bool both_groups = false);
+                        bool both_groups = false,
+                        // diagnostic (prefilter + d_dense): write the bound's error bound instead of the bound
+                        bool dense_err = false);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

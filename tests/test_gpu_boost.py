@@ -162,10 +162,12 @@ def _prefilter_table(rng, n, m, p_missing, low_maf):
                                                    (40_000, 36, 0.0, True), (250_000, 24, 0.0, False),
                                                    (250_000, 20, 0.01, True)])
 def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_maf):
-    """gw_boost_screen without extremes may rule pairs out by the single-precision bound
-    (GW_OPT_BOOST_PREFILTER): the hit list and its FP64 measures must not change, also for
-    thresholds that sit exactly on a pair's measure; and the bound's measured error must stay
-    well inside the slack the screen allows for it."""
+    """gw_boost_screen without extremes rules pairs out by a single-precision bound of the measure plus the
+    bound's own running error bound (GW_OPT_BOOST_PREFILTER, derivation in gw_boost_dev.h): the hit list and
+    its FP64 measures must not change, also for thresholds that sit exactly on a pair's measure; every pair's
+    bound must lie within its error bound of the FP64 measure (the guarantee the screen relies on, and checks
+    itself at run time: GW_OPT_BOOST_PREFILTER_TRIPS stays 0); and the FP64 repeat that a violation would
+    trigger gives the same list."""
     rng = np.random.default_rng(n + 7 * m + int(low_maf))
     codes = _prefilter_table(rng, n, m, p_missing, low_maf)
     u = rng.random(n)
@@ -185,17 +187,21 @@ def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_ma
         exact = t.boost_measures(0, m, 0, m)
         finite = np.sort(exact[np.isfinite(exact)])
         n_sel = nc + nt
-        slack = 2.0 * n_sel * 1e-4 + 0.05
 
-        # the bound itself (diagnostic form)
+        # the bound and its error bound (diagnostic forms)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 2)
         bound = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 3)
+        err_bound = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
-        both = np.isfinite(exact) & np.isfinite(bound)
+        both = np.isfinite(exact) & np.isfinite(bound) & np.isfinite(err_bound)
         assert both.sum() >= 0.9 * np.isfinite(exact).sum()
         err = np.abs(bound[both] - exact[both])
-        # error budget: a quarter of the slack, plus 2e-6 relative for the planted (huge) measures
-        assert np.all(err <= slack / 4 + 2e-6 * np.abs(exact[both])), (err.max(), slack)
+        assert np.all(err <= err_bound[both]), (err.max(), (err / err_bound[both]).max())
+        # ... and for ordinary pairs it is far tighter than the empirical slack (2n * 1e-4 + 0.05) it replaced
+        assert np.median(err_bound[both]) < 0.1 * (2.0 * n_sel * 1e-4 + 0.05)
+        print(f"n={n}: max |bound - measure| / err_bound = {(err / err_bound[both]).max():.3f}, "
+              f"median err_bound = {np.median(err_bound[both]):.4f}")
 
         thresholds = [30.0, float(np.median(finite)), float(finite[int(0.9 * len(finite))]), float(finite[-1]),
                       float(finite[-2]), float(finite[len(finite) // 3]), -1.0e9, 1.0e9]
@@ -207,6 +213,16 @@ def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_ma
             assert vmax is None and vmin is None
             assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
             assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0     # no pair ever left its error bound
+        # the repeat in FP64 that a violation triggers (forced here): same list, and it is counted
+        thr = float(finite[int(0.9 * len(finite))])
+        want_hits, want_n, *_ = t.boost_screen(0, m, 0, m, threshold=thr)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS, 1)
+        hits1, n1, p1, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS, 0)
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 1
+        assert (n1, p1) == (want_n, m * (m - 1) // 2)
+        assert np.array_equal(np.sort(hits1, order=["snp_a", "snp_b"]), np.sort(want_hits, order=["snp_a", "snp_b"]))
         # switched off: still the same
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 0)
         hits0, n0, *_ = t.boost_screen(0, m, 0, m, threshold=30.0, extremes=False)

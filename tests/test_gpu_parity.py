@@ -536,3 +536,4 @@ def test_scan_with_masks_from_the_real_reference_object(oracle, n, m):
         want = tuple(int((codes[r][grp] == c).sum()) for grp in (cases, ctrls) for c in (1, 2, 3, 0))
         assert tuple(int(v) for v in counts[r]) == want
         _assert_stats(stats[r], oracle.assoc_stats(want[:4], want[4:]))
+

@@ -49,6 +49,7 @@ alg = m * (n / 4.0)
 lst = lambda s: [int(x) for x in s.split(",")]
 combos = list(itertools.product(lst(args.unroll), lst(args.threads), lst(args.per_cu), lst(args.lds), lst(args.nt), lst(args.pipe), lst(args.compl)))
 res = {c: [] for c in combos}
+kern = {}
 for rnd in range(args.rounds):
     for c in combos:
         u, th, pc, lds, nt, pipe, cm = c
@@ -65,16 +66,17 @@ for rnd in range(args.rounds):
             t.scan_case_control_device(0, m, base, base + m * 32 if args.stats else None, None)
         ms = t.timer_stop(None) / args.reps
         res[c].append(ms)
+        kern[c] = t.last_scan_kernel()
 probe = []
 for _ in range(3):
     t.timer_start(None)
     nb = t.stream_read_probe(None)
     probe.append(nb / (t.timer_stop(None) * 1e-3) / 1e9)
 print(f"workload {args.workload}: {n} x {m}, algorithmic {alg/1e9:.2f} GB/launch, probe {max(probe):.0f} GB/s")
-print("unroll thr perCU lds nt pipe compl | median ms | min ms | GB/s(min) | %peak")
+print("unroll thr perCU lds nt pipe compl | median ms | min ms | GB/s(min) | %peak | kernel")
 for c, v in sorted(res.items(), key=lambda kv: min(kv[1])):
     med, mn = float(np.median(v)), min(v)
-    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f}")
+    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f} | {kern[c]}")
 # the plain genotype distribution (no masks) on the same table: short-row kernel on / off
 dist_buf = torch.empty(m * 16, dtype=torch.uint8, device="cuda")
 for mode in (1, 0):
