@@ -73,6 +73,10 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=3, help="N > 1: record buffers per piece (gathers in flight)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
                     help="N > 1: RCCL gather to rank 0 (grouped send/recv, one xGMI link per peer) or all_gather")
+    ap.add_argument("--exchange", choices=["torch", "capi"], default="torch",
+                    help="who gathers the records: torch.distributed (RCCL through PyTorch, default) or the C-ABI's own "
+                         "RCCL communicator (gw_comm_gather, the path a C++ host uses; also runs at N = 1, where the "
+                         "gather is the root's own device copy)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 debugging aid for a one-GPU box: every rank opens device 0, the process group is gloo "
                          "and the records travel through host memory -- exercises the sharding / buffering logic, "
@@ -397,6 +401,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
+    comm = None
+    if args.exchange == "capi" and not (args.rehearse_on_one_gpu and world > 1):
+        # the C-ABI's own communicator: rank 0 makes the id, torch.distributed only carries it to the others
+        if world > 1:
+            idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(gw.comm_new_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            comm_id = bytes(idt.cpu().numpy().tobytes())
+        else:
+            comm_id = gw.comm_new_id()
+        comm = gw.GwComm(local_rank, rank, world, comm_id)
+
     workload = args.workload or ("c3" if world == 1 else "c4")
     if workload == "c5":
         out = bench_pairs(args, rank, world, local_rank, dist)
@@ -447,14 +464,20 @@ def main():
     n_chunks = args.chunks if args.chunks > 0 else (2 if world > 1 else 1)
     bounds = shard.chunk_bounds(n_cap, n_chunks)
     n_chunks = len(bounds) - 1
-    n_buf = max(1, args.buffers) if world > 1 else 1
+    exchanging = world > 1 or comm is not None
+    n_buf = max(1, args.buffers) if exchanging else 1
     bufs, gathers, allgather_out = [], [], []
+    recv_flat, events = [], []
     for c in range(n_chunks):
         cap = bounds[c + 1] - bounds[c]
         bufs.append([torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(n_buf)])
-        if world > 1 and args.collective == "gather" and rank == 0 and not rehearse:
+        if world > 1 and args.collective == "gather" and rank == 0 and not rehearse and comm is None:
             gathers.append([[torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(world)]
                             for _ in range(n_buf)])
+        if comm is not None:
+            recv_flat.append([torch.empty(world * cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") if rank == 0 else None
+                              for _ in range(n_buf)])
+            events.append([None] * n_buf)
         if world > 1 and args.collective == "all_gather":
             allgather_out.append([torch.empty(world * cap * RECORD_BYTES, dtype=torch.uint8, device="cuda")
                                   for _ in range(n_buf)])
@@ -465,6 +488,7 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
     assert sptr != 0
+    side = torch.cuda.Stream() if comm is not None else None  # the C-ABI gather's stream (torch's RCCL has its own)
 
     def scan_piece(c, b):
         lo, hi = min(bounds[c], n_local), min(bounds[c + 1], n_local)  # a shard one row short scans one row less
@@ -478,6 +502,15 @@ def main():
     rehearsal_last = {}
 
     def exchange(c, b):
+        if comm is not None:  # gw_comm_gather on a side stream, behind this piece's scan
+            side.wait_stream(stream)
+            cap = bounds[c + 1] - bounds[c]
+            comm.gather(bufs[c][b].data_ptr(), cap * RECORD_BYTES, recv_flat[c][b].data_ptr() if rank == 0 else None, 0,
+                        side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            events[c][b] = ev
+            return None
         if rehearse:  # gloo, through host memory, synchronous: logic check only
             stream.synchronize()
             got, _ = shard.gather_records(dist, bufs[c][b].cpu(), rank, world, dst=0)
@@ -500,8 +533,11 @@ def main():
             if pending[c][b] is not None:
                 pending[c][b].wait()  # GPU-side: the scan stream waits for the gather that last read this buffer
                 pending[c][b] = None
+            if comm is not None and events[c][b] is not None:
+                stream.wait_event(events[c][b])
+                events[c][b] = None
             scan_piece(c, b)
-            if world > 1:
+            if exchanging:
                 pending[c][b] = exchange(c, b)
 
     def drain():
@@ -510,6 +546,9 @@ def main():
                 if pending[c][b] is not None:
                     pending[c][b].wait()
                     pending[c][b] = None
+                if comm is not None and events[c][b] is not None:
+                    stream.wait_event(events[c][b])
+                    events[c][b] = None
 
     for _ in range(args.warmup):
         step()
@@ -589,9 +628,10 @@ def main():
                 "sharding": (f"contiguous SNP ranges of one {n_total}-SNP table, one rank per GPU (rank 0: "
                              f"[{begin}, {begin + n_local}))" if strong else
                              "a full-size table per rank" if world > 1 else "single GPU"),
-                "exchange": (f"RCCL {args.collective} of {RECORD_BYTES} B/SNP to rank 0 inside every step, "
-                             f"{n_chunks} piece(s) per step, {n_buf} buffers per piece (gathers run under the "
-                             f"following scans)") if world > 1 else "none",
+                "exchange": ((f"gw_comm_gather (C-ABI, grouped ncclSend/ncclRecv)" if comm is not None else
+                              f"torch.distributed {args.collective} (RCCL)") +
+                             f" of {RECORD_BYTES} B/SNP to rank 0 inside every step, {n_chunks} piece(s) per step, "
+                             f"{n_buf} buffers per piece (gathers run under the following scans)") if exchanging else "none",
                 "kernel_shape": shape, "stats_dtype": "f64", "git": git_head(),
             },
             "roofline": {
@@ -626,6 +666,13 @@ def main():
                 if strong:
                     ok &= bool(np.array_equal(gc, counts[b0 + lo:b0 + hi]) and np.array_equal(gs, stats[b0 + lo:b0 + hi]))
         out["config"]["rehearsal_gathered_equals_single_scan"] = ok if strong else None
+    if comm is not None:
+        if rank == 0 and out is not None:  # the last step's records as gathered: rank 0's own slice equals what it scanned
+            cap0 = bounds[1] - bounds[0]
+            b_last = (step_no[0] - 1) % n_buf
+            own = recv_flat[0][b_last][:cap0 * RECORD_BYTES]
+            out["config"]["capi_gather_own_slice_intact"] = bool(torch.equal(own, bufs[0][b_last]))
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

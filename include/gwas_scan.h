@@ -252,6 +252,36 @@ int gw_boost_measures(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_be
 int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint16_t *rows,
                                uint32_t *case_blocks, uint32_t *ctrl_blocks);
 
+/* ---- multi-GPU: SNP-range shards + one gather -----------------
+ * Every SNP row is independent (the loop of algorithms/maf_func.cpp:304-314 touches row i and the shared masks
+ * only), so a job shards by contiguous SNP ranges, one process per GPU, each with its own gw_table holding
+ * its rows; the phenotype masks are replicated.  The one exchange step is the gather of the per-SNP records
+ * to one rank.  These entry points let a C or C++ host do all of that without Python: librccl is loaded at
+ * run time (dlopen) the first time a gw_comm_* function is called.
+ *   gw_shard_range   rank r of `world` owns SNPs [begin, end) of n_snps_total (sizes differ by at most one)
+ *   gw_comm_new_id   one rank makes the rendezvous id (ncclGetUniqueId, GW_COMM_ID_BYTES bytes) and hands it
+ *                    to the others by any means (a file, MPI, the launcher's environment)
+ *   gw_comm_create   ncclCommInitRank on `device`; collective over all ranks
+ *   gw_comm_gather   every rank gives `bytes` at d_send, the root receives rank p's slice at d_recv + p * bytes:
+ *                    grouped ncclSend / ncclRecv, i.e. every peer's slice over its own xGMI link; enqueued on
+ *                    `hip_stream` (NULL = the communicator's own stream) behind whatever produced d_send there,
+ *                    not synchronised
+ *   gw_table_stream  the handle's own stream (what NULL means in the *_device scan forms), to enqueue the gather
+ *                    behind a scan
+ * gw_device_malloc / _free / _download: device buffers for hosts without a HIP toolchain of their own. */
+typedef struct gw_comm gw_comm;
+#define GW_COMM_ID_BYTES 128
+int gw_shard_range(uint64_t n_snps_total, int rank, int world, uint64_t *begin, uint64_t *end);
+int gw_comm_new_id(void *id);
+int gw_comm_create(int device, int rank, int world, const void *id, gw_comm **out);
+int gw_comm_destroy(gw_comm *c);
+int gw_comm_gather(gw_comm *c, const void *d_send, size_t bytes, void *d_recv, int root, void *hip_stream);
+int gw_comm_synchronize(gw_comm *c, void *hip_stream);
+int gw_table_stream(gw_table *t, void **hip_stream);
+int gw_device_malloc(int device, size_t bytes, void **d_ptr);
+int gw_device_free(int device, void *d_ptr);
+int gw_device_download(int device, void *host_dst, const void *d_src, size_t bytes, void *hip_stream);
+
 /* ---- measurement ----------------------------------------------------------
  * HIP events on the stream the kernels are launched on (NULL = the handle's
  * stream).  gw_timer_stop synchronises on the stop event and returns the

@@ -88,7 +88,9 @@ EXPORTS = [
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
     "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected",
-    "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_last_scan_kernel", "gw_set_option",
+    "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_last_scan_kernel",
+    "gw_shard_range", "gw_comm_new_id", "gw_comm_create", "gw_comm_destroy", "gw_comm_gather", "gw_comm_synchronize",
+    "gw_table_stream", "gw_device_malloc", "gw_device_free", "gw_device_download", "gw_set_option",
     "gw_get_option", "gw_pack_genotype_row", "gw_header_assign", "gw_build_stream_mask", "gw_stream_blocks",
     "gw_block_blocks",
 ]
@@ -135,6 +137,16 @@ def library() -> C.CDLL:
     L.gw_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.gw_stream_read_probe.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     L.gw_synchronize.argtypes = [vp]
+    L.gw_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.gw_comm_new_id.argtypes = [vp]
+    L.gw_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.gw_comm_destroy.argtypes = [vp]
+    L.gw_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
+    L.gw_comm_synchronize.argtypes = [vp, vp]
+    L.gw_table_stream.argtypes = [vp, C.POINTER(vp)]
+    L.gw_device_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.gw_device_free.argtypes = [C.c_int, vp]
+    L.gw_device_download.argtypes = [C.c_int, vp, vp, C.c_size_t, vp]
     L.gw_last_scan_kernel.argtypes = [vp]
     L.gw_last_scan_kernel.restype = C.c_char_p
     L.gw_set_option.argtypes = [vp, C.c_int, C.c_int64]
@@ -200,6 +212,75 @@ def build_stream_mask(idx, n_samples: int):
     _check(library().gw_build_stream_mask(idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size, n_samples,
                                           _p16(mask), C.byref(cnt)))
     return mask, cnt.value
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    b, e = C.c_uint64(0), C.c_uint64(0)
+    _check(library().gw_shard_range(n_total, rank, world, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+COMM_ID_BYTES = 128
+
+
+class DeviceBuffer:
+    """A plain device allocation through the C-ABI (gw_device_malloc), for callers that have no torch."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self._L = library()
+        self.device, self.nbytes = device, nbytes
+        p = C.c_void_p()
+        _check(self._L.gw_device_malloc(device, nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def download(self, stream: int | None = None) -> np.ndarray:
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        _check(self._L.gw_device_download(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
+        return out
+
+    def close(self):
+        if self.ptr:
+            self._L.gw_device_free(self.device, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_new_id() -> bytes:
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(library().gw_comm_new_id(buf))
+    return buf.raw
+
+
+class GwComm:
+    """The C-ABI's RCCL communicator (gw_comm): gather of equally sized device buffers to a root."""
+
+    def __init__(self, device: int, rank: int, world: int, comm_id: bytes):
+        self._L = library()
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        _check(self._L.gw_comm_create(device, rank, world, C.create_string_buffer(comm_id, COMM_ID_BYTES), C.byref(self._h)))
+
+    def gather(self, d_send: int, nbytes: int, d_recv: int | None, root: int = 0, stream: int | None = None):
+        _check(self._L.gw_comm_gather(self._h, d_send, nbytes, d_recv, root, stream))
+
+    def synchronize(self, stream: int | None = None):
+        _check(self._L.gw_comm_synchronize(self._h, stream))
+
+    def close(self):
+        if self._h:
+            self._L.gw_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GwTable:
@@ -375,6 +456,11 @@ class GwTable:
 
     def synchronize(self):
         _check(self._L.gw_synchronize(self._h))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(self._L.gw_table_stream(self._h, C.byref(s)))
+        return s.value or 0
 
     def last_scan_kernel(self) -> str:
         return self._L.gw_last_scan_kernel(self._h).decode()

@@ -226,6 +226,11 @@ bool complementary(const std::vector<uint16_t> &cs, const std::vector<uint16_t> 
 extern "C" {
 
 const char *gw_last_error(void) { return g_err.c_str(); }
+// for the library's other translation units (gw_comm.cpp): sets the calling thread's message, returns `code`
+int gw_set_error_message(int code, const char *msg) {
+    g_err = msg ? msg : "";
+    return code;
+}
 const char *gw_version(void) { return "libgwscan 0.1 (gfx950)"; }
 
 int gw_device_count(int *count) {
@@ -1085,6 +1090,12 @@ int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
 }
 
 const char *gw_last_scan_kernel(const gw_table *t) { return t ? t->last_scan_kernel : ""; }
+
+int gw_table_stream(gw_table *t, void **hip_stream) {
+    if (!t || !hip_stream) return fail(GW_E_INVALID, "NULL argument");
+    *hip_stream = (void *)t->stream;
+    return GW_OK;
+}
 
 int gw_synchronize(gw_table *t) {
     if (!t) return fail(GW_E_INVALID, "NULL table");

@@ -32,14 +32,28 @@ bool readTfamIndividuals(const std::string &tfam, GeneticData *gd) {
     return true;
 }
 
-bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim) {
+long countTpedMarkers(const std::string &tped) {
+    std::ifstream in(tped.c_str());
+    if (!in.is_open()) return -1;
+    long n = 0;
+    std::string ln;
+    while (std::getline(in, ln))
+        if (!blank(ln)) ++n;
+    return n;
+}
+
+bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim, long first_marker, long n_markers) {
     std::ifstream in(tped.c_str());
     if (!in.is_open()) return false;
+    const long last_marker = n_markers < 0 ? -1 : first_marker + n_markers;  // exclusive; -1 = to the end
     // pass 1: marker ids (tped_genotype_file.cpp:104-125 parseNextMarkerRecord)
     std::vector<std::string> markers;
     std::string ln, chr, rs;
+    long line_no = 0;
     while (std::getline(in, ln)) {
         if (blank(ln)) continue;
+        const long k = line_no++;
+        if (k < first_marker || (last_marker >= 0 && k >= last_marker)) continue;
         std::istringstream p(ln);
         p >> chr >> rs;
         markers.push_back(rs);
@@ -79,11 +93,16 @@ bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim) {
     std::vector<std::string> lines, texts;
     int row = 0;
     bool eof = false;
+    line_no = 0;
     while (!eof) {
         lines.clear();
         while (lines.size() < batch_lines) {
             if (!std::getline(in, ln)) { eof = true; break; }
-            if (!blank(ln)) lines.push_back(ln);
+            if (blank(ln)) continue;
+            const long k = line_no++;
+            if (k < first_marker) continue;
+            if (last_marker >= 0 && k >= last_marker) { eof = true; break; }
+            lines.push_back(ln);
         }
         if (lines.empty()) break;
         texts.resize(lines.size());

@@ -14,6 +14,8 @@
 //   --test-boost-epi       computeBoost: KSA pre-screen of all pairs + exact G test on the hits
 //   --contin-perform       ContingencyPerformance timing harness
 //   --assoc                counts + MAF/HWE/chi-square of every SNP
+//   --world W --rank R --comm-id FILE   (with --assoc) one process per GPU: rank R ingests and scans its SNP
+//                          range of the .tped, the records are gathered to rank 0 over RCCL, rank 0 prints all of them
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -23,6 +25,7 @@
 
 #include "algorithms/epistasis_func.h"
 #include "algorithms/maf_func.h"
+#include "algorithms/sharded_scan.h"
 #include "genetics/genotype/hip_genotype_table.h"
 #include "genetics/individual/tplink_files.h"
 
@@ -31,6 +34,7 @@ using namespace libgwaspp::algorithms;
 
 static void usage() {
     std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] [--scan-window ROWS] [--no-prefetch] "
+                 "[--world W --rank R --comm-id FILE (with --assoc)] "
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
                  "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--contin-perform|--assoc\n";
     std::exit(2);
@@ -44,6 +48,7 @@ int main(int argc, char **argv) {
     std::string tped, tfam, out_path, mode;
     int device = 0, scan_window = 0;
     bool prefetch = true;
+    ShardInfo shard;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if ((a == "-g" || a == "--genotype") && i + 1 < argc) tped = argv[++i];
@@ -52,14 +57,30 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--scan-window" && i + 1 < argc) scan_window = std::atoi(argv[++i]);  // rows per device scan
         else if (a == "--no-prefetch") prefetch = false;
+        else if (a == "--world" && i + 1 < argc) shard.world = std::atoi(argv[++i]);
+        else if (a == "--rank" && i + 1 < argc) shard.rank = std::atoi(argv[++i]);
+        else if (a == "--comm-id" && i + 1 < argc) shard.id_file = argv[++i];
         else if (a == "-t") {}  // transposed input is the only form here
         else if (a.rfind("--", 0) == 0) mode = a;
         else usage();
     }
     if (tped.empty() || tfam.empty() || mode.empty()) usage();
 
+    shard.device = device;
+    const bool sharded = shard.world > 1 || !shard.id_file.empty();
+    if (sharded && (mode != "--assoc" || shard.rank < 0 || shard.rank >= shard.world || (shard.world > 1 && shard.id_file.empty())))
+        usage();
+    long n_total = 0;
+    unsigned long first = 0, last = 0;
+    if (sharded) {
+        n_total = countTpedMarkers(tped);
+        if (n_total < 0) { std::cerr << "cannot read " << tped << std::endl; return 1; }
+        shardRange((unsigned long)n_total, shard.rank, shard.world, first, last);
+    }
     GeneticData gd(eHip2BitStream, device);
-    if (!readTfamIndividuals(tfam, &gd) || !readTpedGenotypes(tped, &gd) || !readTfamCaseControl(tfam, &gd)) {
+    if (!readTfamIndividuals(tfam, &gd) ||
+        !(sharded ? readTpedGenotypes(tped, &gd, '\t', (long)first, (long)(last - first)) : readTpedGenotypes(tped, &gd)) ||
+        !readTfamCaseControl(tfam, &gd)) {
         std::cerr << "cannot read " << tped << " / " << tfam << std::endl;
         return 1;
     }
@@ -145,6 +166,18 @@ int main(int argc, char **argv) {
         computeBoost(&gd, out);
     } else if (mode == "--contin-perform") {
         ContingencyPerformance(&gd, out);
+    } else if (mode == "--assoc" && sharded) {
+        std::vector<uint> counts;
+        std::vector<double> stats;
+        shardedCaseControlScan(&gd, shard, (unsigned long)n_total, counts, stats);
+        if (shard.rank == 0) {
+            *out << std::setprecision(17);
+            for (long i = 0; i < n_total; ++i) {
+                for (int k = 0; k < 8; ++k) *out << (k ? "\t" : "") << counts[(size_t)i * 8 + k];
+                for (int k = 0; k < 8; ++k) *out << "\t" << stats[(size_t)i * 8 + k];
+                *out << "\n";
+            }
+        }
     } else if (mode == "--assoc") {
         HipGenotypeTable &ht = static_cast<HipGenotypeTable &>(gt);
         CaseControlSet &ccs = *gd.getCaseControlSet();

@@ -144,3 +144,38 @@ def test_bench_multi_rank_logic_rehearsed_on_one_gpu():
     assert line["config"]["workload"].startswith("REHEARSAL ON ONE GPU")
     assert line["config"]["rehearsal_gathered_equals_single_scan"] is True
     assert line["roofline"]["kernel"].startswith("gw::k_scan_cc_pipe")
+
+
+def test_c_abi_communicator_with_one_rank():
+    """gw_comm_* (RCCL loaded at run time) with a world of one: the gather is the root's own device copy, enqueued
+    behind the scan on the table's stream (tests/comm_script.py, in a process of its own without torch)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_script.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "comm_script ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_cpp_host_sharded_scan_with_one_rank(tmp_path):
+    """gwas_hip --assoc --world 1: the C++ host's sharded path (gw_shard_range, gw_comm_create, scan on the table's
+    stream, gw_comm_gather, download) prints what the plain --assoc prints."""
+    from golden_util import PERL_DIR
+    cli = os.path.join(ROOT, "libgwaspp_amd", "bin", "gwas_hip")
+    if not os.path.exists(cli):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "libgwaspp_amd", "host"), "-s"], check=True)
+    name = "cc_m24_n1000"
+    base = [cli, "-g", os.path.join(PERL_DIR, name + ".tped"), "-p", os.path.join(PERL_DIR, name + ".tfam")]
+    plain = subprocess.run(base + ["--assoc"], check=True, capture_output=True, text=True).stdout
+    shard = subprocess.run(base + ["--world", "1", "--rank", "0", "--comm-id", str(tmp_path / "id"), "--assoc"], check=True,
+                           capture_output=True, text=True).stdout
+    rows = lambda text: [ln for ln in text.splitlines() if ln.count("\t") == 15]
+    assert len(rows(plain)) == 24 and rows(shard) == rows(plain)
+
+
+def test_bench_exchange_through_the_c_abi_on_one_gpu():
+    """bench.py --exchange capi at N = 1: the C-ABI gather (side stream, events, three record buffers) runs inside every
+    step; rank 0's own slice arrives intact."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--exchange", "capi", "--workload", "c2", "--snps", "60000",
+                        "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["exchange"].startswith("gw_comm_gather")
+    assert line["config"]["capi_gather_own_slice_intact"] is True

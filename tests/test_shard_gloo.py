@@ -120,3 +120,15 @@ def test_two_rank_gather_equals_single_process(oracle):
             b, _ = shard.snp_range(even, r, world)
             want = _records(oracle, seed, b + bounds[c], bounds[c + 1] - bounds[c], n)
             assert np.array_equal(chunked[c][r], want)
+
+
+def test_c_abi_shard_range_equals_the_python_partition():
+    """gw_shard_range (what a C++ host uses, host-only) and shard.snp_range cut a job the same way."""
+    import libgwaspp_amd as gw
+    from libgwaspp_amd import shard
+    for total in (0, 1, 7, 8, 1000, 1_000_000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert gw.shard_range(total, r, world) == shard.snp_range(total, r, world)
+    with pytest.raises(gw.GwError):
+        gw.shard_range(10, 2, 2)
