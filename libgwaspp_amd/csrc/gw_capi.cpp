@@ -84,6 +84,10 @@ struct gw_table {
     uint64_t prefilter_trips = 0;  // screens repeated in FP64 because a pair fell outside the bound's error model
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
     unsigned long long *d_tally = nullptr;
+    void *d_hits_buf = nullptr;    // hit list / dense block of the pair screens, kept between calls (grow-only)
+    size_t hits_buf_bytes = 0;
+    double *d_dense_buf = nullptr;
+    size_t dense_buf_bytes = 0;
 
     // rows packed by gw_table_add_genotype_row, waiting for the next flush
     std::vector<uint16_t> pending;
@@ -135,18 +139,12 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
     // (N > ~320 k): 4 waves per CU, one per SIMD, two 2-unit buffers in flight -- 87 % vs 85 % at c3
     sh.pipeline = t->opt_pipeline < 0 ? ((one_per_cu && !compl_ok && lds) ? 1 : 0) : (t->opt_pipeline && lds && !compl_ok);
     int unroll = t->opt_unroll ? t->opt_unroll : (!lds ? 4 : (one_per_cu ? 2 : 1));
-    // the continuous-stream kernel exists for 1, 2, 4 units and keeps the masks zero-padded to a
-    // whole step in LDS; if that padding no longer fits, fall back to the row-at-a-time kernel
-    if (sh.pipeline) {
-        if (unroll > 4) unroll = 4;
-        const uint32_t step = 64u * (uint32_t)unroll;
-        const size_t padded = (size_t)2 * (((units + step - 1u) / step) * step) * sizeof(gw::u32x4);
-        if (padded > t->lds_cap) sh.pipeline = 0;
-    }
+    // the continuous-stream kernel exists for 1, 2, 4 units and keeps one zero entry behind each mask in LDS
+    if (sh.pipeline && unroll > 4) unroll = 4;
     size_t need = raw_need;
     if (sh.pipeline) {
-        const uint32_t step = 64u * (uint32_t)unroll;
-        need = (size_t)2 * (((units + step - 1u) / step) * step) * sizeof(gw::u32x4);
+        need = (size_t)2 * (units + 1u) * sizeof(gw::u32x4);
+        if (need > t->lds_cap) { sh.pipeline = 0; need = raw_need; }
     }
     if (lds && need > t->lds_cap) lds = false;
     sh.complement = (compl_ok && lds) ? 1 : 0;
@@ -373,6 +371,8 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
     if (t->d_tally) (void)hipFree(t->d_tally);
+    if (t->d_hits_buf) (void)hipFree(t->d_hits_buf);
+    if (t->d_dense_buf) (void)hipFree(t->d_dense_buf);
     if (t->ev_start) (void)hipEventDestroy(t->ev_start);
     if (t->ev_stop) (void)hipEventDestroy(t->ev_stop);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -919,13 +919,33 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     if ((rc = use_device(t))) return rc;
     const unsigned long long init[4] = {0ull, 0ull, 0ull, ~0ull};
     GW_HIP(hipMemcpyAsync(t->d_tally, init, sizeof init, hipMemcpyHostToDevice, t->stream));
+    // result buffers live in the handle and only ever grow: a caller that walks the pair space block by block
+    // (sharded screens) pays for the allocation once
     gw::BoostHit *d_hits = nullptr;
     double *d_dense = nullptr;
-    if (max_hits) GW_HIP(hipMalloc((void **)&d_hits, max_hits * sizeof(gw::BoostHit)));
+    if (max_hits) {
+        const size_t need = max_hits * sizeof(gw::BoostHit);
+        if (need > t->hits_buf_bytes) {
+            if (t->d_hits_buf) GW_HIP(hipFree(t->d_hits_buf));
+            t->d_hits_buf = nullptr;
+            t->hits_buf_bytes = 0;
+            GW_HIP(hipMalloc(&t->d_hits_buf, need));
+            t->hits_buf_bytes = need;
+        }
+        d_hits = static_cast<gw::BoostHit *>(t->d_hits_buf);
+    }
     hipError_t e = hipSuccess;
     if (dense && n_a && n_b) {
-        e = hipMalloc((void **)&d_dense, n_a * n_b * sizeof(double));
-        if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0xFF, n_a * n_b * sizeof(double), t->stream);  // NaN
+        const size_t need = n_a * n_b * sizeof(double);
+        if (need > t->dense_buf_bytes) {
+            if (t->d_dense_buf) GW_HIP(hipFree(t->d_dense_buf));
+            t->d_dense_buf = nullptr;
+            t->dense_buf_bytes = 0;
+            GW_HIP(hipMalloc((void **)&t->d_dense_buf, need));
+            t->dense_buf_bytes = need;
+        }
+        d_dense = t->d_dense_buf;
+        e = hipMemsetAsync(d_dense, 0xFF, need, t->stream);  // NaN
     }
     // FP32 bound first where nobody asked for the extremes: a pair is dropped without its FP64 measure only if
     // bound + err < threshold, err = the bound's own running error bound (gw_boost_dev.h boost_bound).
@@ -962,8 +982,6 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         if (n) e = hipMemcpy(hits, d_hits, n * sizeof(gw::BoostHit), hipMemcpyDeviceToHost);
     }
     if (e == hipSuccess && dense && d_dense) e = hipMemcpy(dense, d_dense, n_a * n_b * sizeof(double), hipMemcpyDeviceToHost);
-    if (d_hits) (void)hipFree(d_hits);
-    if (d_dense) (void)hipFree(d_dense);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return fail(e == hipErrorOutOfMemory ? GW_E_NOMEM : GW_E_HIP, "BOOST pre-screen: %s", hipGetErrorString(e));

@@ -395,22 +395,26 @@ __device__ __forceinline__ void asm_wait_older(u32x4 (&A)[UNROLL], u32x4 (&B)[UN
 
 template <int UNROLL, bool MASK_LDS, bool NT>
 __global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 threads: up to 256 VGPRs for the two buffers
-    extern __shared__ u32x4 lds_masks[];  // [2][steps * STEP] when MASK_LDS, zero past `units`
+    extern __shared__ u32x4 lds_masks[];  // [2][units + 1] when MASK_LDS: entry `units` of each mask is zero
     const uint32_t units = a.units;
     constexpr uint32_t STEP = 64u * UNROLL;
     const uint32_t steps = (units + STEP - 1u) / STEP;
-    const uint32_t padded = steps * STEP;  // <= the zero-padded length of the global masks
+    // A lane past the row's end re-reads the row's last unit against a ZERO mask.  In LDS that is one shared zero
+    // entry behind each mask (index min(u, units)), not a whole zero step: at N = 500 k the two masks then take
+    // 125 056 B of the 160 KiB, which leaves a CU room for a second, small-LDS workgroup next to the scan -- RCCL's
+    // ncclDevKernel_Generic needs 37 664 B.  The global masks are zero-padded to 512 units anyway.
+    const uint32_t mlen = units + 1u;
     const u32x4 *mcase = a.case_mask;
     const u32x4 *mctrl = a.ctrl_mask;
     if (MASK_LDS) {
-        for (uint32_t u = threadIdx.x; u < padded; u += blockDim.x) {  // zero past `units` (a column segment's
-            const u32x4 zero = {0, 0, 0, 0};                              // masks continue with the next segment's)
+        for (uint32_t u = threadIdx.x; u < mlen; u += blockDim.x) {  // zero at `units` (a column segment's masks
+            const u32x4 zero = {0, 0, 0, 0};                           // continue with the next segment's)
             lds_masks[u] = u < units ? a.case_mask[u] : zero;
-            lds_masks[padded + u] = u < units ? a.ctrl_mask[u] : zero;
+            lds_masks[mlen + u] = u < units ? a.ctrl_mask[u] : zero;
         }
         __syncthreads();
         mcase = lds_masks;
-        mctrl = lds_masks + padded;
+        mctrl = lds_masks + mlen;
     }
     const uint32_t lane = threadIdx.x & 63u;
     // the row walk lives in SGPRs: row indices, base addresses and branches are scalar
@@ -430,7 +434,8 @@ __global__ void __launch_bounds__(512) k_scan_cc_pipe(ScanArgs a) {  // <= 512 t
     auto consume = [&](const u32x4 (&A)[UNROLL], const u32x4 (&B)[UNROLL], uint32_t row, uint32_t step) {
 #pragma unroll
         for (int k = 0; k < UNROLL; ++k) {
-            const uint32_t u = step * STEP + 64u * k + lane;
+            const uint32_t u0 = step * STEP + 64u * k + lane;
+            const uint32_t u = MASK_LDS ? min(u0, units) : u0;  // past the end: the zero entry (global masks are zero-padded)
             const u32x4 mc = mcase[u];
             const u32x4 mt = mctrl[u];
             if (k & 1) acc_unit(A[k], B[k], mc, mt, c1);

@@ -43,6 +43,20 @@ double boostMeasureOnePair(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T
 
 // 4x4 tables of every pair i < j, timing harness (:105-135)
 void ContingencyPerformance(GeneticData *gd, std::ostream *out);
+// margin-assisted case/control tables of every pair after selectCaseControl + computeMargins, timing
+// harness (:137-203)
+void ContingencyCCPerformance(GeneticData *gd, std::ostream *out);
+// case/control tables of every pair through the inline-mask getter + the two-locus log-likelihood-ratio
+// test of every pair, timing harness (:307-347).  The harness makes its own CaseControlSet: columns 0, 2, ... 398
+// are cases, 1, 3, ... 399 controls (as far as the table has them).
+void EpistasisPerformance(GeneticData *gd, std::ostream *out);
+// 2 x log-likelihood ratio of the saturated two-locus model against the Kirkwood superposition approximation,
+// from the 3 x 3 case and control tables of a pair.  The library's own pairwise_epi_test
+// (epistasis_func.cpp:723-843) is broken as shipped; this follows the correct statement of
+// the same test, src/test/pairwise.c:50-133.
+double pairwise_epi_test(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T &contin_co);
+// upper tail of chi-square with 4 degrees of freedom = pchisq(x, 4.0, 0, 0) (pairwise.c:44): exp(-x/2)(1 + x/2)
+double chisq4_upper_tail(double x);
 
 }  // namespace algorithms
 }  // namespace libgwaspp

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <set>
 
 #include "genetics/genotype/hip_genotype_table.h"
 
@@ -227,6 +228,151 @@ void ContingencyPerformance(GeneticData *gd, std::ostream *out) {
     }
     *out << "Contingencies " << m << ": " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()
          << " (sum of all cells " << checksum << ")" << std::endl;
+}
+
+void ContingencyCCPerformance(GeneticData *gd, std::ostream *out) {
+    CaseControlSet &ccs = *gd->getCaseControlSet();
+    GenoTable &gt = *gd->getGenotypeTable();
+    const int nIndivids = (int)(ccs.getCaseCount() + ccs.getControlCount());
+    gt.selectCaseControl(ccs);                                    // :151
+    marginal_information *pMargins = nullptr;
+    int m = 0;
+    computeMargins(gt, nIndivids, pMargins, m);                   // :156
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long checksum = 0, n_pairs = 0;
+    if (HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt)) {
+        // the i < j walk of :187-201, a million pairs per launch
+        std::vector<uint> pairs;
+        std::vector<CONTIN_TABLE_T> cs, ct;
+        const size_t batch = 1u << 20;
+        pairs.reserve(2 * batch);
+        auto flush = [&]() {
+            if (pairs.empty()) return;
+            hip->getSelectedCaseControlContingencyTables(pairs.data(), pairs.size() / 2, cs, ct);
+            for (size_t k = 0; k < cs.size(); ++k)
+                for (int c = 0; c < 16; ++c) checksum += cs[k].contin[c] + ct[k].contin[c];
+            n_pairs += cs.size();
+            pairs.clear();
+        };
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) {
+                pairs.push_back((uint)i);
+                pairs.push_back((uint)j);
+                if (pairs.size() == 2 * batch) flush();
+            }
+        flush();
+    } else {
+        CaseControlContingencyTable ccct;
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j, ++n_pairs) {
+                gt.getCaseControlContingencyTable(i, j, pMargins[i], pMargins[j], ccct);
+                for (int c = 0; c < 16; ++c)
+                    checksum += ccct.getCaseContingencyTable()->contin[c] + ccct.getControlContingencyTable()->contin[c];
+            }
+    }
+    delete[] pMargins;
+    // every exact table sums to its group: the checksum is pairs x (cases + controls)
+    *out << "Case/Control Contingencies " << m << ": "
+         << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " (" << n_pairs
+         << " pairs, sum of all cells " << checksum << ")" << std::endl;
+}
+
+double pairwise_epi_test(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T &contin_co) {
+    // src/test/pairwise.c:50-133; the 3 x 3 cells of the 4 x 4 tables (missing calls are outside the test)
+    long s[3][3], t[3][3], both[3][3];
+    long s_a[3] = {0, 0, 0}, s_b[3] = {0, 0, 0}, t_a[3] = {0, 0, 0}, t_b[3] = {0, 0, 0}, all_a[3] = {0, 0, 0},
+         all_b[3] = {0, 0, 0};
+    long ns = 0, nt = 0, n = 0;
+    for (int a = 0; a < 3; ++a) {          // step 1: margins (:70-89)
+        for (int b = 0; b < 3; ++b) {
+            s[a][b] = contin_ca.contin[4 * a + b];
+            t[a][b] = contin_co.contin[4 * a + b];
+            both[a][b] = s[a][b] + t[a][b];
+            s_a[a] += s[a][b];
+            s_b[b] += s[a][b];
+            t_a[a] += t[a][b];
+            t_b[b] += t[a][b];
+            all_a[a] += both[a][b];
+            all_b[b] += both[a][b];
+        }
+        ns += s_a[a];
+        nt += t_a[a];
+        n += all_a[a];
+    }
+    double ll = 0.0, tao = 0.0;
+    for (int a = 0; a < 3; ++a) {          // steps 2 and 3 (:92-131), same operation order
+        const double psa = (double)s_a[a] / all_a[a], pta = 1.0 - psa;
+        for (int b = 0; b < 3; ++b) {
+            const double pab = (double)both[a][b] / all_b[b];
+            const double pbs = (double)s_b[b] / ns, pbt = (double)t_b[b] / nt;
+            if (s[a][b] > 0) ll += s[a][b] * std::log((double)s[a][b] / n);
+            if (t[a][b] > 0) ll += t[a][b] * std::log((double)t[a][b] / n);
+            const double ps = pab * pbs * psa, pt = pab * pbt * pta;
+            tao += ps + pt;
+            if (ps > 0) ll -= s[a][b] * std::log(ps);
+            if (pt > 0) ll -= t[a][b] * std::log(pt);
+        }
+    }
+    ll += n * std::log(tao);
+    return 2.0 * ll;
+}
+
+double chisq4_upper_tail(double x) { return x <= 0.0 ? 1.0 : std::exp(-0.5 * x) * (1.0 + 0.5 * x); }
+
+void EpistasisPerformance(GeneticData *gd, std::ostream *out) {
+    GenoTable &gt = *gd->getGenotypeTable();
+    const int m = gd->getGenotypedMarkersCount(), n = gd->getGenotypedIndividualsCount();
+    CaseControlSet ccs(gt.getColumnSet());                       // :313-324: the harness's own groups
+    std::set<int> cases, ctrls;
+    for (int i = 0; i < 200; ++i) {
+        if ((i << 1) < n) cases.insert(i << 1);
+        if ((i << 1) + 1 < n) ctrls.insert((i << 1) + 1);
+    }
+    ccs.setCases(cases);
+    ccs.setControls(ctrls);
+    const auto t0 = std::chrono::steady_clock::now();
+    double ll_sum = 0.0, p_min = 1.0;
+    unsigned long n_pairs = 0, n_nan = 0;
+    auto test = [&](const CONTIN_TABLE_T &ca, const CONTIN_TABLE_T &co) {
+        const double ll = pairwise_epi_test(ca, co);             // :336-339
+        const double pval = chisq4_upper_tail(ll);
+        if (ll == ll) { ll_sum += ll; p_min = std::min(p_min, pval); } else ++n_nan;
+        ++n_pairs;
+    };
+    if (HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt)) {
+        std::vector<uint> pairs, cs, ct;
+        const size_t batch = 1u << 20;
+        pairs.reserve(2 * batch);
+        auto flush = [&]() {
+            if (pairs.empty()) return;
+            hip->getCaseControlContingencyTables(pairs.data(), pairs.size() / 2, ccs, cs, ct);
+            CONTIN_TABLE_T a, b;
+            for (size_t k = 0; k < pairs.size() / 2; ++k) {
+                std::memcpy(a.contin, &cs[16 * k], sizeof a.contin);
+                std::memcpy(b.contin, &ct[16 * k], sizeof b.contin);
+                test(a, b);
+            }
+            pairs.clear();
+        };
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) {
+                pairs.push_back((uint)i);
+                pairs.push_back((uint)j);
+                if (pairs.size() == 2 * batch) flush();
+            }
+        flush();
+    } else {
+        CaseControlContingencyTable ccct;
+        for (int i = 0; i < m; ++i)
+            for (int j = i + 1; j < m; ++j) {
+                gt.getCaseControlContingencyTable(i, j, ccs, ccct);
+                test(*ccct.getCaseContingencyTable(), *ccct.getControlContingencyTable());
+            }
+    }
+    char buf[160];
+    std::snprintf(buf, sizeof buf, " (%lu pairs, %lu undefined, sum of LLR %.10g, smallest p %.6g)", n_pairs, n_nan, ll_sum, p_min);
+    *out << "Case/Control Contingencies " << m << ": "
+         << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << buf << std::endl;
 }
 
 }  // namespace algorithms

@@ -13,6 +13,8 @@
 //   --epi-debug            case/control tables of every pair, all three getters
 //   --test-boost-epi       computeBoost: KSA pre-screen of all pairs + exact G test on the hits
 //   --contin-perform       ContingencyPerformance timing harness
+//   --contin-cc-perform    ContingencyCCPerformance: margin-assisted case/control tables of every pair
+//   --epi-perform          EpistasisPerformance: case/control tables + two-locus LLR test of every pair
 //   --assoc                counts + MAF/HWE/chi-square of every SNP
 //   --world W --rank R --comm-id FILE   (with --assoc) one process per GPU: rank R ingests and scans its SNP
 //                          range of the .tped, the records are gathered to rank 0 over RCCL, rank 0 prints all of them
@@ -36,7 +38,7 @@ static void usage() {
     std::cerr << "usage: gwas_hip -g <tped> -p <tfam> [-o <out>] [--device N] [--scan-window ROWS] [--no-prefetch] "
                  "[--world W --rank R --comm-id FILE (with --assoc)] "
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
-                 "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--contin-perform|--assoc\n";
+                 "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--contin-perform|--contin-cc-perform|--epi-perform|--assoc\n";
     std::exit(2);
 }
 
@@ -166,6 +168,10 @@ int main(int argc, char **argv) {
         computeBoost(&gd, out);
     } else if (mode == "--contin-perform") {
         ContingencyPerformance(&gd, out);
+    } else if (mode == "--contin-cc-perform") {
+        ContingencyCCPerformance(&gd, out);
+    } else if (mode == "--epi-perform") {
+        EpistasisPerformance(&gd, out);
     } else if (mode == "--assoc" && sharded) {
         std::vector<uint> counts;
         std::vector<double> stats;

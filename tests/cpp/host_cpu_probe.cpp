@@ -5,6 +5,7 @@
 //   host_cpu_probe marginal <8 counts>
 //   host_cpu_probe maf <4 counts>
 //   host_cpu_probe gtest <9 case cells> <9 control cells>   (3x3 tables, no missing calls)
+//   host_cpu_probe llr <9 case cells> <9 control cells>     pairwise_epi_test + chi-square(4) upper tail
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -88,6 +89,21 @@ int main(int argc, char **argv) {
         double measure, z;
         libgwaspp::algorithms::gtestOnePair(ca, co, m1, m2, n, measure, z);
         std::printf("%.17g %.17g %.17g\n", libgwaspp::algorithms::boostMeasureOnePair(ca, co, m1, m2, (int)n), measure, z);
+        return 0;
+    }
+    if (mode == "llr" && argc == 20) {
+        CONTIN_TABLE_T ca, co;
+        ResetContingencyTable(ca);
+        ResetContingencyTable(co);
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                ca.contin[4 * a + b] = std::atoi(argv[2 + 3 * a + b]);
+                co.contin[4 * a + b] = std::atoi(argv[11 + 3 * a + b]);
+            }
+        ca.contin[15] = 7;  // missing-call cells are outside the test
+        co.contin[3] = 5;
+        const double ll = libgwaspp::algorithms::pairwise_epi_test(ca, co);
+        std::printf("%.17g %.17g\n", ll, libgwaspp::algorithms::chisq4_upper_tail(ll));
         return 0;
     }
     if (mode == "maf" && argc == 6) {

@@ -238,3 +238,46 @@ def test_getters_served_from_prefetched_windows(window, tmp_path):
         _run(name_cc, "--test-inline-cc-maf", o, extra=extra)
         assert (_table_lines(open(o + ".case").read()), _table_lines(open(o + ".control").read())) == ref_cc
         assert _run(name_cc, "--assoc", extra=extra) == ref_assoc
+
+
+def test_case_control_contingency_performance_harness():
+    """--contin-cc-perform (ContingencyCCPerformance, epistasis_func.cpp:137-203): selectCaseControl, computeMargins,
+    then the margin-assisted case/control tables of every pair, batched on the device.  Every exact table sums to its
+    group, so the checksum is pairs x (cases + controls)."""
+    for name in ("cc_m24_n1000", "plain_m40_n70"):          # without and with missing calls
+        cases, ctrls = read_tfam_status(name)
+        m = len(read_tped(name))
+        out = _run(name, "--contin-cc-perform")
+        line = [ln for ln in out.splitlines() if ln.startswith(f"Case/Control Contingencies {m}:")][0]
+        pairs = m * (m - 1) // 2
+        assert f"({pairs} pairs, sum of all cells {pairs * (len(cases) + len(ctrls))})" in line
+
+
+def test_epistasis_performance_harness(oracle):
+    """--epi-perform (EpistasisPerformance, epistasis_func.cpp:307-347): the harness's own groups (even columns < 400
+    cases, odd ones controls), the inline-mask case/control tables of every pair and the two-locus LLR test on each.
+    The sum of the LLRs against the oracle's pairwise.c restatement on tables counted from the .tped text."""
+    from text_pairs import joint_counts, row_classes
+    for name in ("cc_m24_n1000", "cc_m6_n70", "plain_m40_n70"):
+        n = int(name.split("_n")[1])
+        lines = read_tped(name)
+        m = len(lines)
+        cls = [row_classes(ln) for ln in lines]
+        cases = np.array([i << 1 for i in range(200) if (i << 1) < n], dtype=np.int64)
+        ctrls = np.array([(i << 1) + 1 for i in range(200) if (i << 1) + 1 < n], dtype=np.int64)
+        total, undefined = 0.0, 0
+        for i in range(m):
+            for j in range(i + 1, m):
+                nine = [4 * a + b for a in range(3) for b in range(3)]
+                cs = joint_counts(cls[i], cls[j], cases)[nine].reshape(3, 3)
+                ct = joint_counts(cls[i], cls[j], ctrls)[nine].reshape(3, 3)
+                ll = oracle.pairwise_llr(cs, ct)
+                if np.isnan(ll):
+                    undefined += 1
+                else:
+                    total += ll
+        out = _run(name, "--epi-perform")
+        line = [ln for ln in out.splitlines() if ln.startswith(f"Case/Control Contingencies {m}:")][0]
+        got = line[line.index("(") + 1:line.index(")")].split(", ")
+        assert got[0] == f"{m * (m - 1) // 2} pairs" and got[1] == f"{undefined} undefined"
+        assert float(got[2].split()[-1]) == pytest.approx(total, rel=1e-8)

@@ -95,3 +95,29 @@ def test_boost_measure_and_gtest_mirror(oracle, probe):
         np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)
         if llr is not None:
             assert got[0] == pytest.approx(llr, rel=1e-10)
+
+
+
+def test_pairwise_epi_test_mirror(oracle, probe):
+    """EpistasisPerformance's per-pair test in the C++ mirror == the oracle's restatement of pairwise.c:50-133, and
+    its chi-square(4) tail == scipy's."""
+    from scipy.stats import chi2
+    rng = np.random.default_rng(3)
+    tables = [(rng.integers(0, 60, size=9), rng.integers(0, 60, size=9)) for _ in range(12)]
+    tables.append((np.array([10, 0, 3, 0, 0, 0, 4, 0, 9]), np.array([8, 0, 2, 0, 0, 0, 5, 0, 7])))   # empty classes
+    for cs, ct in tables:
+        ll, p = (float(v) for v in probe("llr", *cs, *ct)[0].split())
+        want = oracle.pairwise_llr(cs.reshape(3, 3), ct.reshape(3, 3))
+        if np.isnan(want):
+            assert np.isnan(ll)
+            continue
+        assert ll == pytest.approx(want, rel=1e-13, abs=1e-10)
+        assert p == pytest.approx(chi2.sf(max(ll, 0.0), 4), rel=1e-12)
+    # the five literal tables of src/test/pairwise.c:20-37 (LLR and p-values as SURVEY.md section 4 records them)
+    from test_oracle_arith import PAIRWISE_KAT
+    pvals = {"boost0": 0.22759012753331526, "boost1": 9.97784906723507e-07, "boost2": 3.4987703837442206e-06,
+             "biforce1": 6.448641043097075e-08, "biforce2": 1.0796960060009832e-16}
+    for name, cs, ct, llr in PAIRWISE_KAT:
+        ll, p = (float(v) for v in probe("llr", *np.array(cs).reshape(-1), *np.array(ct).reshape(-1))[0].split())
+        assert ll == pytest.approx(llr, rel=1e-12)
+        assert p == pytest.approx(pvals[name], rel=1e-9)
