@@ -69,7 +69,10 @@ def parse_args():
                     help="N > 1: strong = the workload's SNPs are sharded over the ranks (BASELINE config 4); "
                          "weak = every rank scans a full-size table of its own")
     ap.add_argument("--snps", type=int, default=0, help="override the job's SNP count (debug)")
-    ap.add_argument("--chunks", type=int, default=0, help="scan/gather pieces per step (0 = auto: 1, or 2 when N > 1)")
+    ap.add_argument("--chunks", type=int, default=1, help="scan/gather pieces per step")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="compute units the persistent scan leaves free (default: 0 on one GPU, 8 when N > 1 so that "
+                         "RCCL's kernel never has to wait for, or push aside, a scan workgroup)")
     ap.add_argument("--buffers", type=int, default=3, help="N > 1: record buffers per piece (gathers in flight)")
     ap.add_argument("--collective", choices=["gather", "all_gather"], default="gather",
                     help="N > 1: RCCL gather to rank 0 (grouped send/recv, one xGMI link per peer) or all_gather")
@@ -453,6 +456,8 @@ def main():
         table.set_option(capi.OPT_MASK_IN_LDS, args.mask_lds)
     if args.nt >= 0:
         table.set_option(capi.OPT_NONTEMPORAL, args.nt)
+    reserve_cus = args.reserve_cus if args.reserve_cus >= 0 else (8 if world > 1 else 0)
+    table.set_option(capi.OPT_RESERVE_CUS, reserve_cus)
     t_setup = time.perf_counter()
     table.simulate(SEED, begin, 0)           # rows of ONE table: row r of this rank = global SNP begin + r
     table.simulate_phenotype(SEED)           # identical masks on every rank (same seed)
@@ -461,7 +466,7 @@ def main():
     # result buffers (torch = device memory + streams + RCCL plumbing).  A step is cut into n_chunks pieces;
     # each piece has `n_buf` record buffers used round-robin over the steps, so a scan only ever waits for
     # the gather that used its buffer n_buf steps ago.
-    n_chunks = args.chunks if args.chunks > 0 else (2 if world > 1 else 1)
+    n_chunks = max(1, args.chunks)
     bounds = shard.chunk_bounds(n_cap, n_chunks)
     n_chunks = len(bounds) - 1
     exchanging = world > 1 or comm is not None
@@ -605,7 +610,8 @@ def main():
                  "nontemporal": table.get_option(capi.OPT_NONTEMPORAL),
                  "continuous_stream": table.get_option(capi.OPT_PIPELINE),
                  "single_mask": table.get_option(capi.OPT_COMPLEMENT),
-                 "sub_wave_rows": table.get_option(capi.OPT_SHORT_ROWS)}
+                 "sub_wave_rows": table.get_option(capi.OPT_SHORT_ROWS),
+                 "reserved_cus": table.get_option(capi.OPT_RESERVE_CUS)}
         traffic, traffic_note = (pmc_traffic(workload, kernel_name) if n_chunks == 1 and world == 1 and not args.snps
                                  else (None, "PMC figure is per whole-table launch on one GPU"))
         out = {

@@ -336,6 +336,10 @@ typedef enum gw_option {
                                 the masks through L2 (N > ~650 k with arbitrary masks, > ~1.3 M with
                                 complementary ones), segments of 4096 units (524 288 samples); -1 never;
                                 > 0 that many 16-byte units per segment; get returns the segment in use */
+    GW_OPT_RESERVE_CUS = 14, /* compute units the persistent scan grid leaves free (default 0).  A sharded job whose
+                                gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
+                                512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
+                                scan workgroup that has to wait for one finishes its static share of the rows late */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

@@ -30,6 +30,7 @@ OPT_BOOST_MATRIX_CORES = 9
 OPT_SHORT_ROWS = 10
 OPT_COLUMN_SEGMENT = 11
 OPT_BOOST_PREFILTER_TRIPS = 12
+OPT_RESERVE_CUS = 14
 
 
 class GwError(RuntimeError):

@@ -95,7 +95,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0;
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
     size_t raw_bytes = 0;
@@ -159,7 +159,8 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
     int per_cu = t->opt_blocks_per_cu ? t->opt_blocks_per_cu : (one_per_cu ? 1 : (short_rows ? 8 : 4));
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
-    sh.grid_blocks = t->compute_units * per_cu;
+    // GW_OPT_RESERVE_CUS: CUs the persistent grid leaves free (for a collective's kernel running beside the scan)
+    sh.grid_blocks = std::max(1, t->compute_units - t->opt_reserve_cus) * per_cu;
     // short rows with every shape option left on auto: several rows per wave at a time, masks in registers
     if (!seg_units && short_rows && t->opt_short_rows && !t->opt_unroll && !t->opt_threads && t->opt_mask_lds < 0 && t->opt_pipeline < 0 &&
         t->opt_nt && t->opt_complement != 2) {
@@ -1162,6 +1163,10 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
     case GW_OPT_SHORT_ROWS:
         t->opt_short_rows = v ? 1 : 0;
         return GW_OK;
+    case GW_OPT_RESERVE_CUS:
+        if (v < 0 || v >= 128) return fail(GW_E_INVALID, "reserve_cus must be 0 .. 127");
+        t->opt_reserve_cus = (int)v;
+        return GW_OK;
     case GW_OPT_COLUMN_SEGMENT:
         if (v < -1 || v > (1 << 20)) return fail(GW_E_INVALID, "column_segment must be -1 (never), 0 (auto) or a unit count");
         t->opt_segment = (int)v;
@@ -1193,6 +1198,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_PREFILTER_TRIPS: *v = (int64_t)t->prefilter_trips; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
+    case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;
     default: return fail(GW_E_INVALID, "unknown option %d", option);
     }

@@ -134,9 +134,10 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly_before_any_gpu_call():
 
 def test_bench_multi_rank_logic_rehearsed_on_one_gpu():
     """bench.py's own N = 2 step loop (config 4 sharding, ragged shards, two pieces per step, three record
-    buffers per piece) with both ranks on device 0 and a gloo gather: rank 0 checks the gathered records of the
+    buffers per piece, eight CUs left free) with both ranks on device 0 and a gloo gather: rank 0 checks the gathered records of the
     last step against one scan of the whole table."""
-    r = _torchrun(["--rehearse-on-one-gpu", "--snps", "40001", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    r = _torchrun(["--rehearse-on-one-gpu", "--snps", "40001", "--steps", "4", "--warmup", "1", "--chunks", "2",
+                   "--no-cpu-baseline"])
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
@@ -144,6 +145,7 @@ def test_bench_multi_rank_logic_rehearsed_on_one_gpu():
     assert line["config"]["workload"].startswith("REHEARSAL ON ONE GPU")
     assert line["config"]["rehearsal_gathered_equals_single_scan"] is True
     assert line["roofline"]["kernel"].startswith("gw::k_scan_cc_pipe")
+    assert line["config"]["kernel_shape"]["reserved_cus"] == 8
 
 
 def test_c_abi_communicator_with_one_rank():

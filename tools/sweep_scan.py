@@ -30,6 +30,7 @@ ap.add_argument("--lds", default="1")
 ap.add_argument("--nt", default="1")
 ap.add_argument("--pipe", default="-1", help="-1 auto, 0 row-at-a-time, 1 continuous-stream")
 ap.add_argument("--compl", default="1", help="0 never, 1 auto, 2 whenever possible")
+ap.add_argument("--reserve", default="0", help="CUs the persistent grid leaves free")
 ap.add_argument("--stats", type=int, default=1)
 args = ap.parse_args()
 
@@ -47,12 +48,13 @@ base = buf.data_ptr()
 alg = m * (n / 4.0)
 
 lst = lambda s: [int(x) for x in s.split(",")]
-combos = list(itertools.product(lst(args.unroll), lst(args.threads), lst(args.per_cu), lst(args.lds), lst(args.nt), lst(args.pipe), lst(args.compl)))
+combos = list(itertools.product(lst(args.unroll), lst(args.threads), lst(args.per_cu), lst(args.lds), lst(args.nt), lst(args.pipe), lst(args.compl), lst(args.reserve)))
 res = {c: [] for c in combos}
 kern = {}
 for rnd in range(args.rounds):
     for c in combos:
-        u, th, pc, lds, nt, pipe, cm = c
+        u, th, pc, lds, nt, pipe, cm, rsv = c
+        t.set_option(capi.OPT_RESERVE_CUS, rsv)
         t.set_option(capi.OPT_PIPELINE, pipe)
         t.set_option(capi.OPT_COMPLEMENT, cm)
         t.set_option(capi.OPT_UNROLL, u)
@@ -76,7 +78,7 @@ print(f"workload {args.workload}: {n} x {m}, algorithmic {alg/1e9:.2f} GB/launch
 print("unroll thr perCU lds nt pipe compl | median ms | min ms | GB/s(min) | %peak | kernel")
 for c, v in sorted(res.items(), key=lambda kv: min(kv[1])):
     med, mn = float(np.median(v)), min(v)
-    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f} | {kern[c]}")
+    print(f"{c[0]:6d} {c[1]:4d} {c[2]:5d} {c[3]:3d} {c[4]:2d} {c[5]:4d} {c[6]:5d} rsv{c[7]:3d} | {med:9.3f} | {mn:7.3f} | {alg/mn/1e6:8.0f} | {alg/mn/1e6/80:5.1f} | {kern[c]}")
 # the plain genotype distribution (no masks) on the same table: short-row kernel on / off
 dist_buf = torch.empty(m * 16, dtype=torch.uint8, device="cuda")
 for mode in (1, 0):
