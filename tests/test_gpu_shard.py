@@ -181,3 +181,27 @@ def test_bench_exchange_through_the_c_abi_on_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["exchange"].startswith("gw_comm_gather")
     assert line["config"]["capi_gather_own_slice_intact"] is True
+
+
+def test_bench_line_keeps_the_contract():
+    """One JSON line with the keys the driver reads (a small workload; the default run is the 125 GB one)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--steps", "5", "--warmup", "2",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["unit"] == "SNPs/s" and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("c1") and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert rf["kernel"].startswith("gw::k_scan_cc") and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "SNPs/s" and cb["value"] > 0 and cb["gpu_parity_on_sample"] is True
+    assert abs(d["value"] - d["config"]["n_snps_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
