@@ -125,3 +125,18 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([exe, "--host-only"], check=True, capture_output=True, text=True).stdout
     assert "row 0 header 0x7015" in out          # AA first, then AC, then CC
     assert "case mask 0x0055 (4)" in out and "control mask 0x00aa (4)" in out
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py has no CPU path to fall back to: without a GPU it must end non-zero and say why (it is the HIP
+    scan that is measured, never the oracle)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("this machine has a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr and not r.stdout.strip()
+    h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert h.returncode == 0 and "--gpus" in h.stdout and "--workload" in h.stdout
