@@ -80,6 +80,10 @@ def parse_args():
                     help="who gathers the records: torch.distributed (RCCL through PyTorch, default) or the C-ABI's own "
                          "RCCL communicator (gw_comm_gather, the path a C++ host uses; also runs at N = 1, where the "
                          "gather is the root's own device copy)")
+    ap.add_argument("--dist-with-one-rank", action="store_true",
+                    help="N = 1 debugging aid: initialise torch.distributed / RCCL with a world of one and run the exchange "
+                         "step through it (gather to self, barriers, all_reduce) -- exercises the N > 1 code path's calls "
+                         "on one GPU; the JSON line says so")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 debugging aid for a one-GPU box: every rank opens device 0, the process group is gloo "
                          "and the records travel through host memory -- exercises the sharding / buffering logic, "
@@ -395,9 +399,11 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the scan has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    solo_dist = args.dist_with_one_rank and world == 1
+    if world > 1 or solo_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -469,21 +475,21 @@ def main():
     n_chunks = max(1, args.chunks)
     bounds = shard.chunk_bounds(n_cap, n_chunks)
     n_chunks = len(bounds) - 1
-    exchanging = world > 1 or comm is not None
+    exchanging = world > 1 or comm is not None or solo_dist
     n_buf = max(1, args.buffers) if exchanging else 1
     bufs, gathers, allgather_out = [], [], []
     recv_flat, events = [], []
     for c in range(n_chunks):
         cap = bounds[c + 1] - bounds[c]
         bufs.append([torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(n_buf)])
-        if world > 1 and args.collective == "gather" and rank == 0 and not rehearse and comm is None:
+        if (world > 1 or solo_dist) and args.collective == "gather" and rank == 0 and not rehearse and comm is None:
             gathers.append([[torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") for _ in range(world)]
                             for _ in range(n_buf)])
         if comm is not None:
             recv_flat.append([torch.empty(world * cap * RECORD_BYTES, dtype=torch.uint8, device="cuda") if rank == 0 else None
                               for _ in range(n_buf)])
             events.append([None] * n_buf)
-        if world > 1 and args.collective == "all_gather":
+        if (world > 1 or solo_dist) and args.collective == "all_gather":
             allgather_out.append([torch.empty(world * cap * RECORD_BYTES, dtype=torch.uint8, device="cuda")
                                   for _ in range(n_buf)])
     # An explicit (non-default) torch stream: the scans are launched on it through the C-ABI and RCCL
@@ -523,6 +529,8 @@ def main():
                 rehearsal_last[c] = got
             return None
         if args.collective == "gather":
+            if solo_dist:  # shard.gather_records short-cuts a world of one; here the collective itself is wanted
+                return dist.gather(bufs[c][b], gathers[c][b], dst=0, async_op=True)
             _, w = shard.gather_records(dist, bufs[c][b], rank, world, dst=0, async_op=True,
                                         out=gathers[c][b] if rank == 0 else None)
             return w
@@ -559,7 +567,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or solo_dist:
         dist.barrier()
     torch.cuda.synchronize()
     table.timer_start(sptr)
@@ -569,17 +577,17 @@ def main():
     drain()  # every step's records have reached rank 0 before the clock stops
     kernel_ms_total = table.timer_stop(sptr)  # HIP events on the launching stream; syncs on the stop event
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or solo_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or solo_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     launches = args.steps * n_chunks
-    if world > 1:
+    if world > 1 or solo_dist:
         # with the exchange in the loop the compute stream also waits for RCCL; time the scan
         # kernel alone (same launches, no exchange) for the roofline figure
         torch.cuda.synchronize()
@@ -637,7 +645,8 @@ def main():
                 "exchange": ((f"gw_comm_gather (C-ABI, grouped ncclSend/ncclRecv)" if comm is not None else
                               f"torch.distributed {args.collective} (RCCL)") +
                              f" of {RECORD_BYTES} B/SNP to rank 0 inside every step, {n_chunks} piece(s) per step, "
-                             f"{n_buf} buffers per piece (gathers run under the following scans)") if exchanging else "none",
+                             f"{n_buf} buffers per piece (gathers run under the following scans)" +
+                             (" -- ONE RANK, debugging aid" if solo_dist else "")) if exchanging else "none",
                 "kernel_shape": shape, "stats_dtype": "f64", "git": git_head(),
             },
             "roofline": {
@@ -679,7 +688,11 @@ def main():
             own = recv_flat[0][b_last][:cap0 * RECORD_BYTES]
             out["config"]["capi_gather_own_slice_intact"] = bool(torch.equal(own, bufs[0][b_last]))
         comm.close()
-    if world > 1:
+    if solo_dist and out is not None:  # what the gather to self delivered in the last step
+        b_last = (step_no[0] - 1) % n_buf
+        out["config"]["dist_with_one_rank"] = {
+            "backend": dist.get_backend(), "gathered_equals_scanned": bool(torch.equal(gathers[0][b_last][0], bufs[0][b_last]))}
+    if world > 1 or solo_dist:
         dist.barrier()
         dist.destroy_process_group()
     table.close()

@@ -205,3 +205,15 @@ def test_bench_line_keeps_the_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "SNPs/s" and cb["value"] > 0 and cb["gpu_parity_on_sample"] is True
     assert abs(d["value"] - d["config"]["n_snps_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
+def test_bench_exchange_through_torch_rccl_with_one_rank():
+    """bench.py --dist-with-one-rank: the calls of the N > 1 path (init_process_group("nccl"), async dist.gather to
+    rank 0 with three record buffers, Work.wait() on the scan stream, barriers, all_reduce of the time) on the one GPU
+    this box has; the gathered records of the last step equal what was scanned."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-with-one-rank", "--workload", "c2", "--snps", "60000",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["dist_with_one_rank"] == {"backend": "nccl", "gathered_equals_scanned": True}
+    assert "torch.distributed gather (RCCL)" in line["config"]["exchange"]
