@@ -830,15 +830,18 @@ int ensure_selected(gw_table *t) {
     std::copy(cases.begin(), cases.end(), src.begin());
     std::copy(ctrls.begin(), ctrls.end(), src.begin() + (size_t)wc * 32u);
     const uint64_t stride_w = 2ull * (wc + wt);
-    if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
-    if (t->d_mar) { GW_HIP(hipFree(t->d_mar)); t->d_mar = nullptr; }
-    if (t->d_marf) { GW_HIP(hipFree(t->d_marf)); t->d_marf = nullptr; }
-    if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
+    // the compacted planes and their tiled copy depend on the group sizes: kept while those stay the same (new
+    // masks of the same cohort -- another phenotype -- re-use them); the per-SNP margins never change size
+    const bool same_geometry = t->d_cc && t->wc == wc && t->wt == wt;
+    if (!same_geometry) {
+        if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
+        if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
+    }
     if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long)));
     if (m) {
-        GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
-        GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
-        GW_HIP(hipMalloc((void **)&t->d_marf, m * sizeof(gw::SnpMarginF)));
+        if (!t->d_cc) GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
+        if (!t->d_mar) GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
+        if (!t->d_marf) GW_HIP(hipMalloc((void **)&t->d_marf, m * sizeof(gw::SnpMarginF)));
     }
     uint32_t *d_src = nullptr;
     GW_HIP(hipMalloc((void **)&d_src, src.size() * sizeof(uint32_t)));
@@ -880,11 +883,14 @@ int ensure_selected(gw_table *t) {
                                   t->d_marf, t->stream));
         GW_HIP(hipStreamSynchronize(t->stream));
     }
-    t->sel_individs = (uint32_t)(cases.size() + ctrls.size());
-    if (t->d_frac) { GW_HIP(hipFree(t->d_frac)); t->d_frac = nullptr; }
-    if (t->d_xlogx) { GW_HIP(hipFree(t->d_xlogx)); t->d_xlogx = nullptr; }
-    GW_HIP(hipMalloc((void **)&t->d_frac, ((size_t)t->sel_individs + 1u) * sizeof(double)));
-    GW_HIP(hipMalloc((void **)&t->d_xlogx, ((size_t)t->sel_individs + 1u) * sizeof(double)));
+    const uint32_t individs = (uint32_t)(cases.size() + ctrls.size());
+    if (!t->d_frac || individs != t->sel_individs) {  // the k/n and (k/n) log(k/n) tables depend on n only
+        if (t->d_frac) { GW_HIP(hipFree(t->d_frac)); t->d_frac = nullptr; }
+        if (t->d_xlogx) { GW_HIP(hipFree(t->d_xlogx)); t->d_xlogx = nullptr; }
+        GW_HIP(hipMalloc((void **)&t->d_frac, ((size_t)individs + 1u) * sizeof(double)));
+        GW_HIP(hipMalloc((void **)&t->d_xlogx, ((size_t)individs + 1u) * sizeof(double)));
+    }
+    t->sel_individs = individs;
     GW_HIP(gw::launch_boost_tables(t->sel_individs + 1u, t->sel_individs, t->d_frac, t->d_xlogx, t->stream));
     GW_HIP(hipStreamSynchronize(t->stream));
     t->any_missing = false;
@@ -892,7 +898,7 @@ int ensure_selected(gw_table *t) {
         t->any_missing = counts[r * 8 + 3] != 0 || counts[r * 8 + 7] != 0;
     if (m) {  // the MFMA pair kernels read a block-tiled copy
         const size_t bytes = ((m + 63u) / 64u) * 64u * (size_t)((wc + wt) / 4u) * 32u;
-        GW_HIP(hipMalloc((void **)&t->d_cct, bytes));
+        if (!t->d_cct) GW_HIP(hipMalloc((void **)&t->d_cct, bytes));
         GW_HIP(hipMemsetAsync(t->d_cct, 0, bytes, t->stream));
         GW_HIP(gw::launch_retile_cc(t->d_cc, t->cc_stride_w, wc, wt, (uint32_t)m, t->d_cct, t->stream));
         GW_HIP(hipStreamSynchronize(t->stream));

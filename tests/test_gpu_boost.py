@@ -265,3 +265,26 @@ def test_boost_blocks_of_any_geometry_agree_across_kernels(oracle, p_missing):
                 assert n_hits == int((want[ok] > thr).sum()) == len(hits)
                 for h in hits:
                     assert h["measure"] == full[h["snp_a"], h["snp_b"]]
+
+
+def test_new_masks_on_the_same_table_reuse_the_selection_buffers(oracle):
+    """selectCaseControl again with other masks (another phenotype of the same cohort): the compacted planes are
+    re-used while the padded group sizes stay the same and re-made when they change; measures follow the masks."""
+    n, m = 3000, 40
+    rng = np.random.default_rng(17)
+    ts = oracle.pack_codes(_codes(rng, m, n, 0.01), "stream")
+    gs = oracle.geometry_stream(n)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        for neither in (0.1, 0.12, 0.7, 0.1):      # same padded geometry twice, then much smaller groups, then back
+            cs, ct, nc, nt = _masks(oracle, rng, n, neither=neither)
+            t.set_case_control(cs, ct, nc, nt)
+            got = t.boost_measures(0, m, 0, m)
+            want = _pair_matrix(oracle.boost_all_pairs(ts, gs, cs, ct, nc, nt), m)
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            ok = ~np.isnan(want)
+            np.testing.assert_allclose(got[ok], want[ok], rtol=1e-10, atol=1e-10)
+            rec = t.scan_margins()
+            for r in (0, m - 1):
+                ca, co = oracle.stream_cc_dist(ts[r], gs, cs, ct, nc, nt)
+                assert tuple(int(v) for v in rec[r]["cases"]) == tuple(ca) and tuple(int(v) for v in rec[r]["controls"]) == tuple(co)
