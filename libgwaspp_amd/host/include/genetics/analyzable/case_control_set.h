@@ -37,13 +37,9 @@ public:
     const ushort *stream_case_end() const { return stream_case.data() + stream_case.size(); }
     const ushort *stream_control_begin() const { return stream_ctrl.data(); }
     const ushort *stream_control_end() const { return stream_ctrl.data() + stream_ctrl.size(); }
-    uint stream_block_count() const { return (uint)stream_case.size(); }
 
     bool isCase(uint idx) const;
     bool isControl(uint idx) const;
-
-    // bumped on every change: lets a table notice that its device copy is stale
-    unsigned long revision() const { return revision_; }
 
     virtual ~CaseControlSet() {}
 
@@ -53,7 +49,6 @@ protected:
     uint max_index;
     uint case_count, ctrl_count;
     std::vector<ushort> block_case, block_ctrl, stream_case, stream_ctrl;
-    unsigned long revision_;
 };
 
 }  // namespace genetics

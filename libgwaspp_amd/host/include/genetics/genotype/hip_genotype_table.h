@@ -17,6 +17,7 @@
 //   cc (margin-assisted)               exact tables (table5.cpp:989-1150)
 // Errors abort, like the reference's asserts.
 #pragma once
+#include <cstdint>
 #include <string>
 #include <utility>
 #include <future>
@@ -85,12 +86,20 @@ public:
     void setScanWindow(uint rows) { window = rows ? rows : 1; invalidate(); }
     // scan window k+1 on a worker thread while the caller walks window k (on by default)
     void setPrefetch(bool on) { drop_prefetch(); prefetch = on; }
+    // the reference's CaseControlSet has no change counter, so a set edited in place is recognised from its mask
+    // bytes: all of them at selectCaseControl() and at every new window of rows, object + counts + 32 sampled
+    // words per mask on the calls in between (the reference's loops never edit a set mid-walk).  true = compare
+    // all bytes on every getter call (N/4 bytes of host reads per call)
+    void setMaskCheckEveryCall(bool on) { check_every_call = on; }
     gw_table *handle() { settle(); return tbl; }
 
 protected:
     void initialize() override;
     void invalidate();
-    void install(CaseControlSet &ccs);
+    // makes ccs the device's masks unless it already is.  whole = compare every mask byte with the installed
+    // copy; otherwise a per-call check (object, counts, 32 sampled words per mask)
+    void install(CaseControlSet &ccs, bool whole = false);
+    bool masks_unchanged(CaseControlSet &ccs, bool whole);
     void fill_dist_cache(uint rIdx);
     void fill_cc_cache(uint rIdx);
     // the window after the one just served, scanned ahead by a worker thread.  The C-ABI is one-thread-per-
@@ -124,7 +133,10 @@ protected:
 
     // installed masks
     const CaseControlSet *installed;
-    unsigned long installed_rev;
+    uint installed_cases, installed_ctrls;
+    std::vector<ushort> installed_case_mask, installed_ctrl_mask;   // what the device holds (stream packing)
+    uint64_t installed_sample[2];
+    bool check_every_call;
 
     // pair getters: the reference's loops walk (i, j), (i, j+1), ... -- a run of pairs of the same first marker
     // is fetched in one launch (the run grows x4 while the walk stays sequential, 1 .. 4096 pairs)

@@ -13,7 +13,7 @@ uint padded_blocks(uint n, uint per_block_shift) { return (((n >> per_block_shif
 }  // namespace
 
 CaseControlSet::CaseControlSet(const util::indexer *idx)
-    : possible_indices(idx), max_index((uint)idx->included_size() - 1u), case_count(0), ctrl_count(0), revision_(1) {
+    : possible_indices(idx), max_index((uint)idx->included_size() - 1u), case_count(0), ctrl_count(0) {
     const uint n = (uint)idx->included_size();
     block_case.assign(padded_blocks(n, 3), 0);
     block_ctrl.assign(padded_blocks(n, 3), 0);
@@ -31,7 +31,6 @@ void CaseControlSet::fill(const std::set<int> &idx, std::vector<ushort> &block, 
         stream[i >> 4] |= (ushort)(1u << (i & 15));
     }
     count = (uint)idx.size();
-    ++revision_;
 }
 
 void CaseControlSet::setCases(const std::set<int> &idx) { fill(idx, block_case, stream_case, case_count); }
@@ -47,7 +46,6 @@ void CaseControlSet::setAllAsCases() {
     block_case.back() &= (ushort)(0xFFFF >> ((7 - (max_index & 7)) << 1));
     case_count = max_index + 1;
     ctrl_count = 0;
-    ++revision_;
 }
 
 void CaseControlSet::setAllAsControls() {
@@ -58,7 +56,6 @@ void CaseControlSet::setAllAsControls() {
     block_ctrl.back() &= (ushort)(0xFFFF >> ((7 - (max_index & 7)) << 1));
     ctrl_count = max_index + 1;
     case_count = 0;
-    ++revision_;
 }
 
 void CaseControlSet::reset() {
@@ -66,7 +63,6 @@ void CaseControlSet::reset() {
     std::fill(block_ctrl.begin(), block_ctrl.end(), 0);
     std::fill(stream_case.begin(), stream_case.end(), 0);
     std::fill(stream_ctrl.begin(), stream_ctrl.end(), 0);
-    ++revision_;
 }
 
 bool CaseControlSet::isCase(uint i) const { return i <= max_index && (stream_case[i >> 4] >> (i & 15) & 1u); }

@@ -38,7 +38,8 @@ inline void to_freq(const uint *c, frequency_table &ft) {
 HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
     : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
       window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), mar_begin(0), prefetch(true), installed(nullptr),
-      installed_rev(0), row_cached(-1) {
+      installed_cases(0), installed_ctrls(0), check_every_call(false), row_cached(-1) {
+    installed_sample[0] = installed_sample[1] = 0;
     initialize();
 }
 
@@ -225,15 +226,55 @@ void HipGenotypeTable::getGenotypeDistribution(uint rIdx, GenotypeDistribution &
     dist.setDistribution(ft);
 }
 
-void HipGenotypeTable::install(CaseControlSet &ccs) {
-    if (installed == &ccs && installed_rev == ccs.revision()) return;
+// Masks.  The reference's CaseControlSet (analyzable/case_control_set.h:48-91) exposes the mask pointers and the
+// two counts and nothing else: no block count accessor, no change counter.  Everything install() needs follows from
+// those: the block count is a function of the cohort size (case_control_set.cpp:35-52 == gw_stream_blocks), and
+// "did the set change since it was installed" is answered from the mask bytes themselves.  This file compiles
+// unchanged against the reference's own headers (tests/test_build_guards.py).
+namespace {
+// a few words spread over the mask: the per-call check between two whole comparisons
+inline uint64_t mask_sample(const ushort *m, uint blocks) {
+    const uint words = blocks / BLOCKS_PER_PWORD;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(m);
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    const uint step = words > 32u ? words / 32u : 1u;
+    for (uint k = 0; k < words; k += step) {
+        uint64_t v;
+        std::memcpy(&v, w + k, sizeof v);
+        h = (h ^ v) * 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+}  // namespace
+
+bool HipGenotypeTable::masks_unchanged(CaseControlSet &ccs, bool whole) {
+    if (installed != &ccs || installed_cases != ccs.getCaseCount() || installed_ctrls != ccs.getControlCount())
+        return false;
+    const ushort *cs = ccs.stream_case_begin(), *ct = ccs.stream_control_begin();
+    const uint blocks = (uint)installed_case_mask.size();
+    if (whole || check_every_call)
+        return std::memcmp(cs, installed_case_mask.data(), blocks * sizeof(ushort)) == 0 &&
+               std::memcmp(ct, installed_ctrl_mask.data(), blocks * sizeof(ushort)) == 0;
+    return mask_sample(cs, blocks) == installed_sample[0] && mask_sample(ct, blocks) == installed_sample[1];
+}
+
+void HipGenotypeTable::install(CaseControlSet &ccs, bool whole) {
+    if (masks_unchanged(ccs, whole)) return;
     drop_prefetch();
     run.valid = false;
-    die_unless_ok(gw_table_set_case_control(tbl, ccs.stream_case_begin(), ccs.stream_control_begin(),
-                                            ccs.stream_block_count(), ccs.getCaseCount(), ccs.getControlCount()),
+    // the set's own block count (case_control_set.cpp:35-52); the C-ABI refuses one that is not the table's
+    const uint blocks = gw_stream_blocks(ccs.getMaximumIndex() + 1u);
+    const ushort *cs = ccs.stream_case_begin(), *ct = ccs.stream_control_begin();
+    die_unless_ok(gw_table_set_case_control(tbl, cs, ct, blocks, ccs.getCaseCount(), ccs.getControlCount()),
                   "gw_table_set_case_control");
     installed = &ccs;
-    installed_rev = ccs.revision();
+    installed_cases = ccs.getCaseCount();
+    installed_ctrls = ccs.getControlCount();
+    installed_case_mask.assign(cs, cs + blocks);
+    installed_ctrl_mask.assign(ct, ct + blocks);
+    installed_sample[0] = mask_sample(cs, blocks);
+    installed_sample[1] = mask_sample(ct, blocks);
     nCaseCount = ccs.getCaseCount();
     nControlCount = ccs.getControlCount();
     nIndivids = nCaseCount + nControlCount;
@@ -245,7 +286,7 @@ void HipGenotypeTable::selectCaseControl(CaseControlSet &ccs) {
     // the reference compacts cases and controls into dense planes here
     // (table5.cpp:443-575, 6.7 s for 10k x 50k); on the GPU the masks are applied
     // inline at full bandwidth, so "select" only installs them
-    install(ccs);
+    install(ccs, true);
 }
 
 void HipGenotypeTable::fill_cc_cache(uint rIdx) {
@@ -278,7 +319,8 @@ void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControl
 
 void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs,
                                                           CaseControlGenotypeDistribution &ccgd) {
-    install(ccs);
+    // every mask byte is compared when a new window of rows is about to be scanned, the sampled check in between
+    install(ccs, rIdx < cc_begin || rIdx >= cc_begin + cc_count);
     getCaseControlGenotypeDistribution(rIdx, ccgd);
 }
 
@@ -372,7 +414,8 @@ void HipGenotypeTable::pair_cc(uint r1, uint r2, CONTIN_TABLE_T &cs, CONTIN_TABL
 
 void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, CaseControlSet &ccs,
                                                       CaseControlContingencyTable &ccct) {
-    install(ccs);
+    install(ccs, !(run.valid && run.masked && run.first == rIdx1 && rIdx2 >= run.second_begin &&
+                   rIdx2 < run.second_begin + run.count));  // whole comparison whenever a launch follows
     CONTIN_TABLE_T cs, ct;
     pair_cc(rIdx1, rIdx2, cs, ct);  // masks before decoding: table5.cpp:823-829
     ccct.setMarkerAIndex(rIdx1);
@@ -413,7 +456,7 @@ void HipGenotypeTable::getCaseControlContingencyTable(uint rIdx1, uint rIdx2, co
 void HipGenotypeTable::getCaseControlContingencyTables(const uint *pairs, size_t n_pairs, CaseControlSet &ccs,
                                                        std::vector<uint> &cases, std::vector<uint> &ctrls) {
     settle();
-    install(ccs);
+    install(ccs, true);
     cases.resize(n_pairs * 16);
     ctrls.resize(n_pairs * 16);
     die_unless_ok(gw_pair_case_control_contingency(tbl, pairs, n_pairs, cases.data(), ctrls.data()),

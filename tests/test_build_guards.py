@@ -5,7 +5,11 @@
    util/table/table.h:69 and the virtual operator() at :53) has an identically typed `override` in
    libgwaspp_amd/host/include/genetics/genotype/hip_genotype_table.h -- parsed from the reference's own
    headers, so it runs only where /root/reference exists (never on the GPU box).
-2. The ISA guard of the pipelined scan (libgwaspp_amd/csrc/check_isa.py): passes on the object the
+2. host/src/hip_genotype_table.cpp compiles UNCHANGED against the reference's own headers (reference include
+   directories in front of this repo's mirror): `g++ -std=gnu++14 -fsyntax-only`.  The reference's
+   common_genotype_func.h:36-37 includes Rmath.h, which this image lacks; for this SYNTAX check only, a
+   one-declaration Rmath.h is written to a temporary directory (it pins nothing and is no oracle).
+3. The ISA guard of the pipelined scan (libgwaspp_amd/csrc/check_isa.py): passes on the object the
    Makefile built and catches a tampered pipeline."""
 import copy
 import importlib.util
@@ -71,6 +75,49 @@ def test_every_reference_pure_virtual_has_an_identically_typed_override():
     assert not missing, f"no identically typed override in hip_genotype_table.h for: {missing}"
     # operator()(r, c) is virtual with a body in the reference (table.h:53): overridden with the same type
     assert "DataBlock operator()(int, int)" in over or "D operator()(int, int)" in over
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine")
+def test_subclass_compiles_unchanged_against_the_reference_headers(tmp_path):
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    (tmp_path / "Rmath.h").write_text("double pchisq(double, double, int, int);\n")
+    host = os.path.join(ROOT, "libgwaspp_amd", "host")
+    cmd = ["g++", "-std=gnu++14", "-fsyntax-only", "-Wall", "-H",
+           "-I" + REF, "-I" + os.path.join(REF, "libgwaspp"), "-I" + str(tmp_path),
+           "-I" + os.path.join(host, "include"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(host, "src", "hip_genotype_table.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert " error: " not in r.stderr
+    # -H lists every header opened: the table interface and CaseControlSet came from the reference tree,
+    # only hip_genotype_table.h itself from this repo's mirror directory
+    opened = [ln.lstrip(". ").strip() for ln in r.stderr.splitlines() if ln.startswith(".")]
+    for name in ("genetics/genotype/geno_table.h", "genetics/analyzable/case_control_set.h",
+                 "genetics/genotype/single_marker_analyzable.h", "genetics/genotype/pairwise_marker_analyzable.h",
+                 "genetics/genotype/case_control_selectable.h", "util/table/table.h"):
+        hits = [h for h in opened if h.endswith(name)]
+        assert hits and all(h.startswith(REF) for h in hits), (name, hits)
+    mirror = [h for h in opened if h.startswith(os.path.join(host, "include"))]
+    assert [os.path.basename(h) for h in mirror] == ["hip_genotype_table.h"], mirror
+
+
+def test_mirror_case_control_set_offers_nothing_the_reference_class_lacks():
+    """The subclass may only use what analyzable/case_control_set.h:48-91 declares; the mirror keeps no extras
+    that could creep back in (round 2: revision(), stream_block_count())."""
+    with open(os.path.join(ROOT, "libgwaspp_amd", "host", "include", "genetics", "analyzable",
+                           "case_control_set.h")) as f:
+        text = f.read()
+    public = text[text.index("public:"):text.index("protected:")]
+    names = set(re.findall(r"(\w+)\s*\(", public))
+    allowed = {"CaseControlSet", "getPossibleIndices", "getMaximumIndex", "getCaseCount", "getControlCount",
+               "getTotalCount", "setCases", "setControls", "setAllAsCases", "setAllAsControls", "control_begin",
+               "control_end", "case_begin", "case_end", "stream_case_begin", "stream_case_end",
+               "stream_control_begin", "stream_control_end", "isCase", "isControl", "reset",
+               "data", "size"}      # data()/size(): std::vector calls inside the inline bodies
+    assert names <= allowed, sorted(names - allowed)
 
 
 def _check_isa():
