@@ -340,6 +340,11 @@ typedef enum gw_option {
                                 gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
                                 512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
                                 scan workgroup that has to wait for one finishes its static share of the rows late */
+    GW_OPT_DEFER_RECORDS = 15, /* rows up to ~100 k samples: 1 = nothing is written while the table is being read; a wave
+                                parks the six sums of its finished rows in LDS and, after its last row, runs the FP64
+                                epilogue over all of them and writes its records in one burst (launches are cut
+                                into pieces that fit the LDS).  Same results bit for bit.  get returns whether the
+                                current table / shape uses it */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

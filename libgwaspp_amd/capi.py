@@ -31,6 +31,7 @@ OPT_SHORT_ROWS = 10
 OPT_COLUMN_SEGMENT = 11
 OPT_BOOST_PREFILTER_TRIPS = 12
 OPT_RESERVE_CUS = 14
+OPT_DEFER_RECORDS = 15
 
 
 class GwError(RuntimeError):

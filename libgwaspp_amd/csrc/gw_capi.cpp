@@ -95,7 +95,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = 0;
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
     size_t raw_bytes = 0;
@@ -123,6 +123,8 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
     //   short rows (N <= ~32 k): 256-thread workgroups, 8 per CU.
     gw::ScanShape sh{};
     sh.compute_units = t->compute_units;
+    sh.reserve_cus = std::min(std::max(t->opt_reserve_cus, 0), t->compute_units - 1);
+    sh.lds_cap = t->lds_cap;
     sh.nontemporal = t->opt_nt;
     const bool want_lds = (t->opt_mask_lds < 0) ? true : (t->opt_mask_lds != 0);
     // single-mask kernel when the control mask is the complement of the case mask
@@ -160,7 +162,13 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
     per_cu = std::max(1, std::min(per_cu, lds_limit));
     sh.block_threads = threads;
     // GW_OPT_RESERVE_CUS: CUs the persistent grid leaves free (for a collective's kernel running beside the scan)
-    sh.grid_blocks = std::max(1, t->compute_units - t->opt_reserve_cus) * per_cu;
+    // GW_OPT_DEFER_RECORDS: row-at-a-time kernel with both masks in LDS and room for at least one parked group of 64
+    // rows per wave beside them (fewer workgroups per CU where that is what it takes)
+    const size_t with_park = need + (size_t)(threads / 64) * 1536u;
+    sh.defer = (!seg_units && t->opt_defer && lds && !sh.complement && !sh.pipeline && sh.nontemporal && (unroll == 1 || unroll == 2) &&
+                with_park <= t->lds_cap) ? 1 : 0;
+    if (sh.defer) per_cu = std::max(1, std::min(per_cu, (int)(t->lds_cap / with_park)));
+    sh.grid_blocks = (t->compute_units - sh.reserve_cus) * per_cu;
     // short rows with every shape option left on auto: several rows per wave at a time, masks in registers
     if (!seg_units && short_rows && t->opt_short_rows && !t->opt_unroll && !t->opt_threads && t->opt_mask_lds < 0 && t->opt_pipeline < 0 &&
         t->opt_nt && t->opt_complement != 2) {
@@ -171,7 +179,8 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
         sh.lds_bytes = 0;
         sh.unroll = 1;
         sh.block_threads = 256;
-        sh.grid_blocks = t->compute_units * t->opt_blocks_per_cu;  // 0 = as many as the kernel's registers allow
+        sh.grid_blocks = (t->compute_units - sh.reserve_cus) * t->opt_blocks_per_cu;  // 0 = as many as the kernel's registers allow
+        sh.defer = t->opt_defer ? 1 : 0;
     }
     return sh;
 }
@@ -1166,6 +1175,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_matrix_cores must be 0, 1 or 2");
         t->opt_boost_mfma = (int)v;
         return GW_OK;
+    case GW_OPT_DEFER_RECORDS:
+        t->opt_defer = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_SHORT_ROWS:
         t->opt_short_rows = v ? 1 : 0;
         return GW_OK;
@@ -1203,6 +1215,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_PREFILTER: *v = t->opt_prefilter; return GW_OK;
     case GW_OPT_BOOST_PREFILTER_TRIPS: *v = (int64_t)t->prefilter_trips; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
+    case GW_OPT_DEFER_RECORDS: *v = sh.defer; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

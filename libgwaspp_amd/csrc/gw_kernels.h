@@ -36,7 +36,10 @@ struct ScanShape {
     int short_rows;     // 1: rows of <= 256 units, a sub-wave of 16 or 32 lanes per row (k_scan_cc_sub; 256 threads, no LDS)
     int grid_blocks;    // persistent workgroups (k_scan_cc_sub: 0 = as many as fit)
     int compute_units;
-    size_t lds_bytes;
+    int reserve_cus;    // CUs the persistent grids leave free (GW_OPT_RESERVE_CUS)
+    int defer;          // 1: records written in one burst at the end of the launch (k_scan_cc / k_scan_cc_sub <.., DEFER>)
+    size_t lds_bytes;   // the masks' share of the dynamic LDS
+    size_t lds_cap;     // dynamic LDS a workgroup may ask for on this device
 };
 
 // case/control scan: counts[n_rows][8], stats[n_rows][8] (stats may be null)

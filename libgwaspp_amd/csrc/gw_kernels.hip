@@ -24,6 +24,7 @@
 // (the all-pairs BOOST path is in gw_boost*.hip)
 #include "gw_kernels.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 
@@ -164,6 +165,8 @@ struct ScanArgs {
     double *stats;
     uint32_t *raw;        // column-segmented scan: the six sums of this segment go here instead ([row][6])
     int raw_accumulate;   // ... added to what earlier segments left
+    uint32_t defer_flushes;  // DEFER kernels: 64-row groups a wave can park in LDS (the launch is sized to fit)
+    uint32_t defer_lds_off;  // ... and where the parking area starts in the dynamic LDS (u32 index, behind the masks)
 };
 
 // ---- row epilogue shared by both scan kernels (table5.cpp:647-653 + section 5 of DESIGN.md)
@@ -200,7 +203,13 @@ __device__ __forceinline__ void finish_row(const ScanArgs &a, uint32_t r, const 
 // control masks (staged once per workgroup in LDS, or read through L2 when
 // they do not fit) and keeps six 32-bit popcounts; a DPP wave reduction ends
 // the row, and the FP64 epilogue runs for 64 finished rows at a time.
-template <int UNROLL, bool MASK_LDS, bool NT>
+// DEFER: nothing is written while the table is being read.  A wave's finished rows (six sums each, parked one per
+// lane as before) go to LDS 64 at a time -- [wave][flush][6][64] u32, each lane reads back only what it wrote, no
+// barrier -- and when the wave has read its last row it runs the FP64 epilogue over everything it parked and emits
+// its records in one burst.  Why: profiles/r02_short_rows_store_ablation.txt -- a record line written back from L2
+// between the reads of the genotype stream costs about six read bytes per byte; the same stores are free while the
+// lines stay in L2.  The launch is sized by the host so that a wave never has more than a.defer_flushes groups.
+template <int UNROLL, bool MASK_LDS, bool NT, bool DEFER = false>
 __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     extern __shared__ u32x4 lds_masks[];  // [2][units] when MASK_LDS
     const uint32_t units = a.units;
@@ -227,7 +236,7 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
     // finished) and the FP64 epilogue runs once per 64 rows with every lane
     // busy, instead of once per row on lane 0 while the wave's loads drain.
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t my_row = 0xFFFFFFFFu, slot = 0;
+    uint32_t my_row = 0xFFFFFFFFu, slot = 0, flush = 0;
 
     for (uint32_t r = gwave; r < a.n_rows; r += total_waves) {
         const u32x4 *p0 = a.table + (a.row_begin + r) * a.row_stride_u;
@@ -262,9 +271,28 @@ __global__ void __launch_bounds__(1024) k_scan_cc(ScanArgs a) {
         }
         my_row = park ? r : my_row;
         if (++slot == 64u) {
-            finish_row(a, my_row, mine);  // all 64 lanes hold a row
+            if (DEFER) {
+                uint32_t *pk = reinterpret_cast<uint32_t *>(lds_masks) + a.defer_lds_off +
+                               ((threadIdx.x >> 6) * a.defer_flushes + flush) * 384u + lane;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) pk[64 * j] = mine[j];
+                ++flush;
+            } else {
+                finish_row(a, my_row, mine);  // all 64 lanes hold a row
+            }
             my_row = 0xFFFFFFFFu;
             slot = 0;
+        }
+    }
+    if (DEFER) {
+        // row of (flush f, lane l) = gwave + (64 f + l) * total_waves: the order the wave walked them in
+        for (uint32_t f = 0; f < flush; ++f) {
+            const uint32_t *pk = reinterpret_cast<const uint32_t *>(lds_masks) + a.defer_lds_off +
+                                 ((threadIdx.x >> 6) * a.defer_flushes + f) * 384u + lane;
+            uint32_t sums[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) sums[j] = pk[64 * j];
+            finish_row(a, gwave + (64u * f + lane) * total_waves, sums);
         }
     }
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
@@ -544,9 +572,12 @@ __device__ __forceinline__ uint32_t row16_sum_dpp(uint32_t v) {
     return v;
 }
 
-template <int G, int STEPS, bool PACK>
+template <int G, int STEPS, bool PACK, bool DEFER = false>
 __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
     static_assert(G == 16 || G == 32, "sub-wave of 16 or 32 lanes per row");
+    extern __shared__ uint32_t lds_park[];  // DEFER (see k_scan_cc): [wave][flush][NP][64], NP = 3 packed or 6 sums
+    constexpr uint32_t NP = PACK ? 3u : 6u;
+    uint32_t flush = 0;
     constexpr uint32_t RW = 64 / G;  // rows per wave and batch
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t grp = lane / G, li = lane % G;
@@ -603,7 +634,14 @@ __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
         }
         my_row = park ? row : my_row;
         if (++slot == (uint32_t)G) {
-            if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
+            if (DEFER) {
+                uint32_t *pk = lds_park + ((threadIdx.x >> 6) * a.defer_flushes + flush) * (NP * 64u) + lane;
+#pragma unroll
+                for (uint32_t j = 0; j < NP; ++j) pk[64u * j] = PACK ? (mine[j] | (mine[3 + j] << 16)) : mine[j];
+                ++flush;
+            } else if (my_row != 0xFFFFFFFFu) {
+                finish_row(a, my_row, mine);
+            }
             my_row = 0xFFFFFFFFu;
             slot = 0;
         }
@@ -624,6 +662,21 @@ __global__ void __launch_bounds__(256) k_scan_cc_sub(ScanArgs a) {
             if (b >= n_batches) break;
         }
     }
+    if (DEFER) {
+        // (flush f, lane (grp, li)) holds batch gwave + (G f + li) * total_waves, row = batch * RW + grp
+        for (uint32_t f = 0; f < flush; ++f) {
+            const uint32_t *pk = lds_park + ((threadIdx.x >> 6) * a.defer_flushes + f) * (NP * 64u) + lane;
+            uint32_t sums[6];
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j) {
+                const uint32_t v = pk[64u * j];
+                sums[j] = PACK ? (v & 0xFFFFu) : v;
+                sums[3 + j] = PACK ? (v >> 16) : pk[64u * (3u + j)];
+            }
+            const uint32_t row = (gwave + ((uint32_t)G * f + li) * total_waves) * RW + grp;
+            if (row < a.n_rows) finish_row(a, row, sums);
+        }
+    }
     if (my_row != 0xFFFFFFFFu) finish_row(a, my_row, mine);
 }
 
@@ -638,25 +691,85 @@ static void note_kernel(const char *fmt, ...) {
 }
 static const char *tf(bool b) { return b ? "true" : "false"; }
 
+// workgroups of k_scan_cc_sub a CU holds (registers; <= 8), per instantiation and device
+template <int G, int STEPS, bool PACK, bool DEFER>
+static int sub_resident() {
+    static int resident[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!resident[dev]) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_cc_sub<G, STEPS, PACK, DEFER>, 256, 0) != hipSuccess || n < 1) n = 2;
+        resident[dev] = n > 8 ? 8 : n;
+    }
+    return resident[dev];
+}
+
 template <int G, int STEPS, bool PACK>
 static hipError_t launch_scan_sub_p(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
-    int grid = sh.grid_blocks;
-    if (grid <= 0) {  // auto: as many persistent workgroups as the registers let a CU hold
-        static int resident = 0;
-        if (!resident) {
-            int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_cc_sub<G, STEPS, PACK>, 256, 0) != hipSuccess || n < 1) n = 2;
-            resident = n > 8 ? 8 : n;
-        }
-        grid = sh.compute_units * resident;
+    const int cus = sh.compute_units > sh.reserve_cus ? sh.compute_units - sh.reserve_cus : 1;
+    if (!sh.defer) {
+        int grid = sh.grid_blocks;  // 0 = auto: as many persistent workgroups as the registers let a CU hold
+        if (grid <= 0) grid = cus * sub_resident<G, STEPS, PACK, false>();
+        note_kernel("gw::k_scan_cc_sub<%d, %d, %s, false>", G, STEPS, tf(PACK));
+        hipLaunchKernelGGL((k_scan_cc_sub<G, STEPS, PACK, false>), dim3(grid), dim3(256), 0, stream, args);
+        return hipGetLastError();
     }
-    note_kernel("gw::k_scan_cc_sub<%d, %d, %s>", G, STEPS, tf(PACK));
-    hipLaunchKernelGGL((k_scan_cc_sub<G, STEPS, PACK>), dim3(grid), dim3(256), 0, stream, args);
-    return hipGetLastError();
+    // records deferred to the end of the launch: the wave's rows are parked in LDS in groups of 64; a launch takes
+    // as many rows as the parking area of the resident workgroups holds, longer scans go in pieces
+    constexpr uint32_t RW = 64 / G, GROUP_BYTES = (PACK ? 3u : 6u) * 256u;
+    const int per_cu = sh.grid_blocks > 0 ? std::max(1, sh.grid_blocks / cus) : sub_resident<G, STEPS, PACK, true>();
+    const int grid = cus * per_cu;
+    const uint32_t total_waves = (uint32_t)grid * 4u;
+    const uint32_t f_max = std::max<uint32_t>(1u, (uint32_t)(sh.lds_cap / (size_t)per_cu) / (4u * GROUP_BYTES));
+    const uint64_t piece_rows = (uint64_t)total_waves * 64u * f_max;
+    note_kernel("gw::k_scan_cc_sub<%d, %d, %s, true>", G, STEPS, tf(PACK));
+    for (uint64_t r0 = 0; r0 < args.n_rows; r0 += piece_rows) {
+        ScanArgs a = args;
+        a.n_rows = (uint32_t)std::min<uint64_t>(piece_rows, args.n_rows - r0);
+        a.row_begin = args.row_begin + r0;
+        a.counts = args.counts + r0 * 8u;
+        a.stats = args.stats ? args.stats + r0 * 8u : nullptr;
+        const uint32_t n_batches = (a.n_rows + RW - 1u) / RW;
+        const uint32_t per_wave = (n_batches + total_waves - 1u) / total_waves;
+        a.defer_flushes = std::max(1u, (per_wave + (uint32_t)G - 1u) / (uint32_t)G);   // <= f_max by construction
+        hipLaunchKernelGGL((k_scan_cc_sub<G, STEPS, PACK, true>), dim3(grid), dim3(256),
+                           (size_t)4u * a.defer_flushes * GROUP_BYTES, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 template <int G, int STEPS>
 static hipError_t launch_scan_sub(const ScanArgs &args, const ScanShape &sh, bool pack, hipStream_t stream) {
     return pack ? launch_scan_sub_p<G, STEPS, true>(args, sh, stream) : launch_scan_sub_p<G, STEPS, false>(args, sh, stream);
+}
+
+// k_scan_cc with the records deferred (see the kernel): pieces sized to the LDS left beside the masks
+template <int UNROLL>
+static hipError_t launch_scan_defer(const ScanArgs &args, const ScanShape &sh, hipStream_t stream) {
+    const uint32_t waves = (uint32_t)sh.block_threads / 64u, total_waves = (uint32_t)sh.grid_blocks * waves;
+    const int per_cu = std::max(1, sh.grid_blocks / std::max(1, sh.compute_units - sh.reserve_cus));
+    const size_t room = sh.lds_cap / (size_t)per_cu > sh.lds_bytes ? sh.lds_cap / (size_t)per_cu - sh.lds_bytes : 0;
+    const uint32_t f_max = (uint32_t)(room / ((size_t)waves * 1536u));
+    if (f_max == 0) return hipErrorInvalidValue;   // scan_shape only asks for this where one group per wave fits
+    const uint64_t piece_rows = (uint64_t)total_waves * 64u * f_max;
+    note_kernel("gw::k_scan_cc<%d, true, true, true>", UNROLL);
+    for (uint64_t r0 = 0; r0 < args.n_rows; r0 += piece_rows) {
+        ScanArgs a = args;
+        a.n_rows = (uint32_t)std::min<uint64_t>(piece_rows, args.n_rows - r0);
+        a.row_begin = args.row_begin + r0;
+        a.counts = args.counts + r0 * 8u;
+        a.stats = args.stats ? args.stats + r0 * 8u : nullptr;
+        const uint32_t per_wave = (a.n_rows + total_waves - 1u) / total_waves;
+        a.defer_flushes = std::max(1u, (per_wave + 63u) / 64u);
+        a.defer_lds_off = (uint32_t)(sh.lds_bytes / 4u);
+        hipLaunchKernelGGL((k_scan_cc<UNROLL, true, true, true>), dim3(sh.grid_blocks), dim3(sh.block_threads),
+                           sh.lds_bytes + (size_t)waves * a.defer_flushes * 1536u, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <int UNROLL, bool MASK_LDS, bool NT>
@@ -665,8 +778,10 @@ static hipError_t launch_scan_inst(const ScanArgs &args, const ScanShape &sh, hi
         note_kernel("gw::k_scan_cc_pipe<%d, %s, %s>", UNROLL <= 4 ? UNROLL : 4, tf(MASK_LDS), tf(NT));
         hipLaunchKernelGGL((k_scan_cc_pipe<(UNROLL <= 4 ? UNROLL : 4), MASK_LDS, NT>), dim3(sh.grid_blocks),
                            dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
+    } else if (sh.defer && MASK_LDS && NT && (UNROLL == 1 || UNROLL == 2)) {
+        return launch_scan_defer<(UNROLL == 2 ? 2 : 1)>(args, sh, stream);
     } else {
-        note_kernel("gw::k_scan_cc<%d, %s, %s>", UNROLL, tf(MASK_LDS), tf(NT));
+        note_kernel("gw::k_scan_cc<%d, %s, %s, false>", UNROLL, tf(MASK_LDS), tf(NT));
         hipLaunchKernelGGL((k_scan_cc<UNROLL, MASK_LDS, NT>), dim3(sh.grid_blocks),
                            dim3(sh.block_threads), MASK_LDS ? sh.lds_bytes : 0, stream, args);
     }
@@ -794,6 +909,8 @@ hipError_t prepare_scan_kernels(size_t max_lds_bytes) {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<2>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<4>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc_compl<8>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<1, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_cc<2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     if ((e = prepare_u<1>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = prepare_u<2>(max_lds_bytes)) != hipSuccess) return e;
     if ((e = prepare_u<4>(max_lds_bytes)) != hipSuccess) return e;

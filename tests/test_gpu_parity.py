@@ -2,6 +2,8 @@
 the CPU oracle and with the reference's golden files.  Integer counts are
 bit-exact; FP64 statistics within rel 1e-10 (BASELINE.json north_star).
 Needs a real MI355X: pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -511,22 +513,23 @@ def test_column_segmented_scan(oracle, n, m, seg):
 
 
 # --------------------------------------------------------------------------
-# masks made by the REAL reference CaseControlSet (oracle/_ref, compiled from the reference's own
-# case_control_set.cpp + index_set.cpp in the build container; the .so travels to the GPU box)
+# masks made by the REAL reference CaseControlSet: tests/golden/ref_ccs/masks.npz holds the bytes behind
+# stream_case_begin() / stream_control_begin() of the reference object (written in the build container by
+# tests/golden/ref_ccs/make_ref_ccs.py from the reference's own case_control_set.cpp compiled in place); only that
+# data travels to the GPU box
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("n,m", [(70, 20), (1000, 64), (4097, 33), (10_000, 200)])
 def test_scan_with_masks_from_the_real_reference_object(oracle, n, m):
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref/libref_ccs.so did not travel with this snapshot")
+    fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ccs", "masks.npz")
+    with np.load(fixture, allow_pickle=False) as z:
+        key = f"scan{n}x{m}"
+        cases, ctrls = z[key + "_cases"], z[key + "_ctrls"]
+        sc, st, cnt = z[key + "_stream_case"], z[key + "_stream_ctrl"], z[key + "_counts"]
     rng = np.random.default_rng(3 * n + m)
     codes = _random_codes(rng, m, n, p_missing=0.03)
     ts = oracle.pack_codes(codes, "stream")
-    gs = oracle.geometry_stream(n)
-    status = rng.integers(0, 3, size=n)          # 0 control, 1 case, 2 neither
-    cases = np.flatnonzero(status == 1).astype(np.int32)
-    ctrls = np.flatnonzero(status == 0).astype(np.int32)
-    _, _, sc, st, cnt = oracle.ref_ccs(n, cases, ctrls)   # stream_case_begin() / stream_control_begin() bytes
     nc, nt = int(cnt[0]), int(cnt[1])
+    assert nc == cases.size and nt == ctrls.size
     with gw.GwTable(n, m) as t:
         t.upload_rows(0, ts)
         t.set_case_control(sc, st, nc, nt)
