@@ -105,10 +105,20 @@ def kernel_source_sha16():
 
 
 def git_head():
+    """HEAD of the tree this run was built from: asked from git where the checkout is (the build container), otherwise
+    read from libgwaspp_amd/GIT_HEAD, which __graft_entry__.build() / the csrc Makefile stamp at build time -- the GPU
+    box receives a snapshot without .git."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                           timeout=10).stdout.strip()
+        if h:
+            return h
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "libgwaspp_amd", "GIT_HEAD")) as f:
+            return (f.read().strip() or None)
+    except OSError:
         return None
 
 
@@ -261,69 +271,91 @@ def side_workload(name, steps, warmup):
                 "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "kernel": t.last_scan_kernel()}
 
 
-def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, with_cpu_baseline=True):
+def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, with_cpu_baseline=True, comm=None):
     """--workload c5: the BOOST / KSA pre-screen over every SNP pair (computeBoost,
     algorithms/epistasis_func.cpp:349-506).  A step = one screen of the whole pair space; the
-    triangle is sharded over the ranks by row blocks (strong scaling: the pair count is fixed),
-    every rank holds the whole table, and the hit lists are all-gathered at the end of a step."""
+    triangle is sharded over the ranks by row blocks (gw_shard_pair_blocks; strong scaling: the pair
+    count is fixed), every rank holds the whole table, each rank appends its hits to a fixed-capacity
+    list in HBM (gw_boost_screen_device: nothing comes back to the host inside a step) and the lists are
+    all-gathered at the end of the step (RCCL through torch.distributed, or gw_comm_allgather with
+    --exchange capi)."""
     import numpy as np
     import torch
     import libgwaspp_amd as gw
-    from libgwaspp_amd import shard
+    from libgwaspp_amd import capi
 
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
+    rehearse = args.rehearse_on_one_gpu and world > 1
     n_samples, n_snps, text = WORKLOADS["c5"]
     if args.snps and args.workload == "c5":
         n_snps = args.snps
     table = gw.GwTable(n_samples, n_snps, device=local_rank)
-    table.simulate(SEED, 0, 0)
-    table.simulate_phenotype(SEED)
-    blocks = []
-    for a, na in sorted(shard.pair_row_blocks(n_snps, rank, world, block=2048)):  # adjacent row blocks -> one launch
-        if blocks and blocks[-1][0] + blocks[-1][1] == a:
-            blocks[-1] = (blocks[-1][0], blocks[-1][1] + na)
-        else:
-            blocks.append((a, na))
+    table.simulate(SEED, 0, 0)               # every rank generates the same table (counter-based RNG); a job
+    table.simulate_phenotype(SEED)           # with ingested rows replicates them with gw_table_replicate instead
+    blocks = gw.shard_pair_blocks(n_snps, rank, world, block=2048)
     cap = 1 << 18
+    list_bytes = capi.BOOST_LIST_HEADER_BYTES + 16 * cap
+    d_list = torch.zeros(list_bytes, dtype=torch.uint8, device="cuda")
+    d_all = torch.zeros(world * list_bytes, dtype=torch.uint8, device="cuda") if (world > 1 or comm is not None) else d_list
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    sptr = stream.cuda_stream
     table.boost_screen(0, min(64, n_snps), 0, min(64, n_snps))  # compaction + margins (untimed setup)
+    host_lists = {}
 
     def step():
-        hits, total, pairs = [], 0, 0
+        table.boost_list_init(d_list.data_ptr(), sptr)
         for a, na in blocks:
-            h, n_hits, n_pairs, _, _ = table.boost_screen(a, na, a, n_snps - a, threshold=30.0, max_hits=cap,
-                                                          extremes=False)  # as computeBoost reports: hits only
-            hits.append(h)
-            total += n_hits
-            pairs += n_pairs
-        mine = np.concatenate(hits) if hits else np.zeros(0, dtype=[("snp_a", "u4"), ("snp_b", "u4"), ("measure", "f8")])
-        if world > 1:  # fixed-size, padded hit lists: one all-gather per step
-            buf = torch.zeros(cap * 16 + 16, dtype=torch.uint8, device="cuda")
-            raw = torch.from_numpy(mine[:cap].view(np.uint8).copy())
-            buf[16:16 + raw.numel()] = raw.cuda()
-            buf[:8] = torch.tensor([min(len(mine), cap)], dtype=torch.int64).view(torch.uint8).cuda()
-            out = torch.empty(world * buf.numel(), dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(out, buf)
-        return total, pairs
+            table.boost_screen_device(a, na, a, n_snps - a, d_list.data_ptr(), cap, 30.0, sptr)  # as computeBoost: threshold 30
+        if world > 1 or comm is not None:  # fixed-size hit lists: one all-gather per step, enqueued behind the screens
+            if rehearse:  # gloo, through host memory: logic check only
+                stream.synchronize()
+                parts = [torch.empty(list_bytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, d_list.cpu())
+                host_lists["all"] = parts
+            elif comm is not None:
+                comm.allgather(d_list.data_ptr(), list_bytes, d_all.data_ptr(), sptr)
+            else:
+                dist.all_gather_into_tensor(d_all, d_list)
 
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    table.timer_start(sptr)
     t0 = time.perf_counter()
     for _ in range(steps):
-        n_hits, n_pairs = step()
+        step()
+    kernel_ms_total = table.timer_stop(sptr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # what the last step left: every rank's header (hits, pairs, pairs outside the pre-filter's error model)
+    if rehearse:
+        raws = [p.numpy() for p in host_lists["all"]]
+    else:
+        whole = d_all.cpu().numpy()
+        raws = [whole[r * list_bytes:(r + 1) * list_bytes] for r in range(world)]
+    parsed = [capi.parse_boost_list(r, cap) for r in raws]
+    n_hits = sum(p[1] for p in parsed)
+    n_pairs = sum(p[2] for p in parsed)
+    if any(p[3] for p in parsed) or any(p[1] > cap for p in parsed):
+        raise SystemExit("bench.py: a hit list overflowed or the pre-filter's error model was violated "
+                         f"(hits {[p[1] for p in parsed]}, capacity {cap}, outside-model pairs {[p[3] for p in parsed]})")
     if world > 1:
-        agg = torch.tensor([elapsed, float(n_pairs), float(n_hits)], dtype=torch.float64, device="cuda")
-        tmax = agg[:1].clone()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg[1:], op=dist.ReduceOp.SUM)
-        elapsed, n_pairs, n_hits = float(tmax.item()), int(agg[1].item()), int(agg[2].item())
+        elapsed = float(tmax.item())
+    kernel_name = table.last_boost_kernel()
+    rehearsal_ok = None
+    if rehearse and rank == 0:  # the union of the ranks' lists == the single-process screen of the whole triangle
+        got = np.sort(np.concatenate([p[0] for p in parsed]), order=["snp_a", "snp_b"])
+        want, wh, wp, _, _ = table.boost_screen(0, n_snps, 0, n_snps, threshold=30.0, max_hits=cap, extremes=False)
+        want = np.sort(want, order=["snp_a", "snp_b"])
+        rehearsal_ok = bool(wh == n_hits and wp == n_pairs and np.array_equal(got, want))
     out = None
     if rank == 0:
         per_step = elapsed / steps
@@ -335,15 +367,23 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i8 x i8 -> i32 (counts), f64 (measure)",
             "data": "synthetic",
-            "config": {"workload": text, "n_samples": n_samples, "n_snps": n_snps, "pairs": n_pairs,
-                       "hits_over_30": n_hits, "sharding": "row blocks of 2048 SNPs in snake order, table replicated",
-                       "exchange": "all-gather of the hit lists" if world > 1 else "none", "stats_dtype": "f64"},
+            "config": {"workload": ("REHEARSAL ON ONE GPU (gloo, host-staged exchange; not a measurement): " if rehearse else "") + text,
+                       "n_samples": n_samples, "n_snps": n_snps, "pairs": n_pairs,
+                       "hits_over_30": n_hits, "sharding": "row blocks of 2048 SNPs in snake order (gw_shard_pair_blocks), table replicated",
+                       "exchange": (("gw_comm_allgather (C-ABI, ncclAllGather)" if comm is not None else
+                                     "torch.distributed all_gather_into_tensor (RCCL)") +
+                                    f" of the fixed-capacity device hit lists ({list_bytes} B per rank) inside every step"
+                                    if (world > 1 or comm is not None) else "none"),
+                       "rehearsal_union_equals_single_screen": rehearsal_ok,
+                       "stats_dtype": "f64", "git": git_head()},
             "roofline": {"bound": "mfma", "achieved": 2.0 * macs / per_step / 1e12, "peak": MFMA_I8_PEAK_TOPS,
                          "unit": "TOP/s (int8, 2 ops per multiply-add; wall time of the whole screen incl. the "
                                  "per-pair bound / measure epilogue and host round trips)",
                          "frac": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
-                         "kernel": "gw::k_boost_mfma_seq<true, 2, 2>",
-                         "note": "algorithmic MACs only (sample padding to 1024 per group not counted)"},
+                         "kernel": kernel_name, "kernel_ms": kernel_ms_total / steps,
+                         "launches_per_step": len(blocks),
+                         "note": "algorithmic MACs only (sample padding to 1024 per group not counted); kernel_ms = HIP "
+                                 "events on the launching stream around the timed steps / steps"},
             "cpu_baseline": None,
         }
         if world == 1 and with_cpu_baseline and not args.no_cpu_baseline:
@@ -425,7 +465,9 @@ def main():
 
     workload = args.workload or ("c3" if world == 1 else "c4")
     if workload == "c5":
-        out = bench_pairs(args, rank, world, local_rank, dist)
+        out = bench_pairs(args, rank, world, local_rank, dist, comm=comm)
+        if comm is not None:
+            comm.close()
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -703,12 +745,13 @@ def main():
         if not args.no_extra:
             extra = {"c2": side_workload("c2", args.steps, args.warmup),
                      "n10k": side_workload("n10k", args.steps, args.warmup)}
-            c5 = bench_pairs(args, 0, 1, local_rank, None, steps=3, warmup=1, with_cpu_baseline=False)
+            c5 = bench_pairs(args, 0, 1, local_rank, None, steps=3, warmup=1, with_cpu_baseline=not args.no_cpu_baseline)
             extra["c5"] = {"workload": c5["config"]["workload"], "ms_per_step": c5["ms_per_step"],
                            "value": c5["value"], "unit": c5["unit"], "pairs": c5["config"]["pairs"],
                            "hits_over_30": c5["config"]["hits_over_30"],
                            "mfma_int8_TOPs": c5["roofline"]["achieved"], "frac": c5["roofline"]["frac"],
-                           "bound": "mfma", "kernel": c5["roofline"]["kernel"], "steps": c5["steps"]}
+                           "bound": "mfma", "kernel": c5["roofline"]["kernel"], "kernel_ms": c5["roofline"]["kernel_ms"],
+                           "steps": c5["steps"], "cpu_baseline": c5["cpu_baseline"]}
             out["extra_workloads"] = extra
     if out is not None:
         print(json.dumps(out))

@@ -242,6 +242,25 @@ typedef struct gw_boost_hit {
 int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
                     double threshold, gw_boost_hit *hits, uint64_t max_hits, uint64_t *n_hits,
                     uint64_t *n_pairs, double *max_measure, double *min_measure);
+/* Device-resident form, for callers that walk the pair space block by block and keep the hits in HBM (the
+ * sharded screen: every rank appends the hits of its row blocks to one list and the lists are all-gathered,
+ * SURVEY.md 8e "C5").  d_list is a caller-owned device buffer of GW_BOOST_LIST_HEADER_BYTES + capacity *
+ * sizeof(gw_boost_hit) bytes:
+ *     uint64 n_hits      hits found by all calls since gw_boost_list_init (may exceed capacity: the list is full)
+ *     uint64 n_pairs     pairs evaluated
+ *     uint64 aux[2]      pre-filter on (default): aux[0] = pairs whose FP64 measure fell outside the single-precision
+ *                        bound's error model -- must be 0, otherwise repeat with GW_OPT_BOOST_PREFILTER 0 (the host form
+ *                        does that by itself); pre-filter off: the ordered maximum / minimum of the measures
+ *     gw_boost_hit hits[capacity]   in no particular order
+ * gw_boost_list_init zeroes the header.  gw_boost_screen_device enqueues the screen of the block on `hip_stream`
+ * (NULL = the handle's stream) and does not synchronise; the first call after a mask or data change also runs
+ * selectCaseControl's compaction and computeMargins (synchronous, on the handle's stream). */
+#define GW_BOOST_LIST_HEADER_BYTES 32
+int gw_boost_list_init(gw_table *t, void *d_list, void *hip_stream);
+int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
+                           double threshold, void *d_list, uint64_t capacity, void *hip_stream);
+/* the kernel instantiation the handle's last pair screen was dispatched to, as rocprofv3 prints it */
+const char *gw_last_boost_kernel(const gw_table *t);
 /* every measure of a (small) block, row-major n_a x n_b; NaN where i >= j */
 int gw_boost_measures(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
                       double *measures);
@@ -266,20 +285,40 @@ int gw_table_download_selected(gw_table *t, uint64_t snp_begin, uint64_t n_rows,
  *                    grouped ncclSend / ncclRecv, i.e. every peer's slice over its own xGMI link; enqueued on
  *                    `hip_stream` (NULL = the communicator's own stream) behind whatever produced d_send there,
  *                    not synchronised
+ *   gw_comm_allgather  every rank gives `bytes` at d_send and receives rank p's slice at d_recv + p * bytes
+ *                    (ncclAllGather; a world of one copies).  The pair screen's exchange step: every rank ends up
+ *                    with every rank's fixed-capacity hit list (SURVEY.md 8e "C5")
+ *   gw_comm_broadcast  `bytes` at d_buf on the root reach d_buf on every rank (ncclBroadcast): replicates packed
+ *                    rows, e.g. the 250 MB table of the pair screen, from the rank that ingested them
  *   gw_table_stream  the handle's own stream (what NULL means in the *_device scan forms), to enqueue the gather
  *                    behind a scan
  * gw_device_malloc / _free / _download: device buffers for hosts without a HIP toolchain of their own. */
 typedef struct gw_comm gw_comm;
 #define GW_COMM_ID_BYTES 128
 int gw_shard_range(uint64_t n_snps_total, int rank, int world, uint64_t *begin, uint64_t *end);
+/* The pair space {(i, j): i < j} of the BOOST screen (computeBoost's loop, algorithms/epistasis_func.cpp:393-486)
+ * sharded over `world` ranks: the rows i are cut into blocks of `block` SNPs dealt in snake order (0..W-1, W-1..0,
+ * ...; block k holds about block x (n_snps - k block) pairs, so the triangle is balanced to < 1 %).  The rank
+ * screens [a_begin[k], +n_a[k]) x [a_begin[k], n_snps) for each of its entries (adjacent blocks come merged).
+ * *n_blocks = entries the rank has; at most `capacity` are written.  Every rank holds the whole table
+ * (gw_table_replicate). */
+int gw_shard_pair_blocks(uint64_t n_snps, uint32_t block, int rank, int world, uint64_t *a_begin, uint64_t *n_a,
+                         size_t capacity, size_t *n_blocks);
+/* rows (and row headers) of the root's table to the same-sized tables of all ranks: one ncclBroadcast of the HBM
+ * rows over xGMI -- the replication step of the pair screen (250 MB at 100 k SNPs x 10 k samples).  Collective;
+ * synchronises `hip_stream` (NULL = the handle's). */
+int gw_table_replicate(gw_table *t, gw_comm *c, int root, void *hip_stream);
 int gw_comm_new_id(void *id);
 int gw_comm_create(int device, int rank, int world, const void *id, gw_comm **out);
 int gw_comm_destroy(gw_comm *c);
 int gw_comm_gather(gw_comm *c, const void *d_send, size_t bytes, void *d_recv, int root, void *hip_stream);
+int gw_comm_allgather(gw_comm *c, const void *d_send, size_t bytes, void *d_recv, void *hip_stream);
+int gw_comm_broadcast(gw_comm *c, void *d_buf, size_t bytes, int root, void *hip_stream);
 int gw_comm_synchronize(gw_comm *c, void *hip_stream);
 int gw_table_stream(gw_table *t, void **hip_stream);
 int gw_device_malloc(int device, size_t bytes, void **d_ptr);
 int gw_device_free(int device, void *d_ptr);
+int gw_device_memset(int device, void *d_ptr, int value, size_t bytes, void *hip_stream);
 int gw_device_download(int device, void *host_dst, const void *d_src, size_t bytes, void *hip_stream);
 
 /* ---- measurement ----------------------------------------------------------
@@ -343,8 +382,9 @@ typedef enum gw_option {
     GW_OPT_DEFER_RECORDS = 15, /* rows up to ~100 k samples: 1 = nothing is written while the table is being read; a wave
                                 parks the six sums of its finished rows in LDS and, after its last row, runs the FP64
                                 epilogue over all of them and writes its records in one burst (launches are cut
-                                into pieces that fit the LDS).  Same results bit for bit.  get returns whether the
-                                current table / shape uses it */
+                                into pieces that fit the LDS).  Same results bit for bit.  -1 (default) auto = rows of
+                                at most 80 units (N <= 10 k) when one call's records exceed the 256 MB Infinity
+                                Cache; 0 never.  get returns whether a whole-table scan with statistics uses it */
     GW_OPT_PIPELINE = 6      /* continuous-stream kernel (next item's loads in flight while the current one
                                 is consumed, across row boundaries; inline-asm loads + counted waits):
                                 -1 (default) auto = where the masks allow one workgroup per CU only

@@ -89,7 +89,9 @@ EXPORTS = [
     "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
-    "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected",
+    "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected", "gw_boost_list_init",
+    "gw_boost_screen_device", "gw_last_boost_kernel", "gw_shard_pair_blocks", "gw_table_replicate",
+    "gw_comm_allgather", "gw_comm_broadcast", "gw_device_memset",
     "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_last_scan_kernel",
     "gw_shard_range", "gw_comm_new_id", "gw_comm_create", "gw_comm_destroy", "gw_comm_gather", "gw_comm_synchronize",
     "gw_table_stream", "gw_device_malloc", "gw_device_free", "gw_device_download", "gw_set_option",
@@ -135,6 +137,16 @@ def library() -> C.CDLL:
                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f64p, f64p]
     L.gw_boost_measures.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, f64p]
     L.gw_table_download_selected.argtypes = [vp, C.c_uint64, C.c_uint64, u16p, u32p, u32p]
+    L.gw_boost_list_init.argtypes = [vp, vp, vp]
+    L.gw_boost_screen_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, vp, C.c_uint64, vp]
+    L.gw_last_boost_kernel.argtypes = [vp]
+    L.gw_last_boost_kernel.restype = C.c_char_p
+    L.gw_shard_pair_blocks.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                       C.c_size_t, C.POINTER(C.c_size_t)]
+    L.gw_table_replicate.argtypes = [vp, vp, C.c_int, vp]
+    L.gw_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    L.gw_comm_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.gw_device_memset.argtypes = [C.c_int, vp, C.c_int, C.c_size_t, vp]
     L.gw_timer_start.argtypes = [vp, vp]
     L.gw_timer_stop.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.gw_stream_read_probe.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
@@ -222,7 +234,27 @@ def shard_range(n_total: int, rank: int, world: int):
     return b.value, e.value
 
 
+def shard_pair_blocks(n_snps: int, rank: int, world: int, block: int = 2048):
+    """[(a_begin, n_a), ...]: the rank's row blocks of the pair triangle (gw_shard_pair_blocks; adjacent blocks merged)."""
+    L = library()
+    n = C.c_size_t(0)
+    _check(L.gw_shard_pair_blocks(n_snps, block, rank, world, None, None, 0, C.byref(n)))
+    a, na = (C.c_uint64 * max(1, n.value))(), (C.c_uint64 * max(1, n.value))()
+    _check(L.gw_shard_pair_blocks(n_snps, block, rank, world, a, na, n.value, C.byref(n)))
+    return [(int(a[k]), int(na[k])) for k in range(n.value)]
+
+
 COMM_ID_BYTES = 128
+BOOST_LIST_HEADER_BYTES = 32
+BOOST_HIT_DTYPE = np.dtype([("snp_a", np.uint32), ("snp_b", np.uint32), ("measure", np.float64)])
+
+
+def parse_boost_list(raw: np.ndarray, capacity: int):
+    """(hits, n_hits, n_pairs, aux0) of one device hit list downloaded as bytes (gw_boost_screen_device's layout)."""
+    head = raw[:BOOST_LIST_HEADER_BYTES].view(np.uint64)
+    n_hits, n_pairs, aux0 = int(head[0]), int(head[1]), int(head[2])
+    hits = raw[BOOST_LIST_HEADER_BYTES:BOOST_LIST_HEADER_BYTES + 16 * capacity].view(BOOST_HIT_DTYPE)[:min(n_hits, capacity)]
+    return hits, n_hits, n_pairs, aux0
 
 
 class DeviceBuffer:
@@ -269,6 +301,12 @@ class GwComm:
 
     def gather(self, d_send: int, nbytes: int, d_recv: int | None, root: int = 0, stream: int | None = None):
         _check(self._L.gw_comm_gather(self._h, d_send, nbytes, d_recv, root, stream))
+
+    def allgather(self, d_send: int, nbytes: int, d_recv: int, stream: int | None = None):
+        _check(self._L.gw_comm_allgather(self._h, d_send, nbytes, d_recv, stream))
+
+    def broadcast(self, d_buf: int, nbytes: int, root: int = 0, stream: int | None = None):
+        _check(self._L.gw_comm_broadcast(self._h, d_buf, nbytes, root, stream))
 
     def synchronize(self, stream: int | None = None):
         _check(self._L.gw_comm_synchronize(self._h, stream))
@@ -428,6 +466,21 @@ class GwTable:
                                        C.byref(vmin) if extremes else None))
         return (hits[:min(nh.value, max_hits)], nh.value, npairs.value, vmax.value if extremes else None,
                 vmin.value if extremes else None)
+
+    def boost_list_init(self, d_list: int, stream: int | None = None):
+        _check(self._L.gw_boost_list_init(self._h, d_list, stream))
+
+    def boost_screen_device(self, a_begin: int, n_a: int, b_begin: int, n_b: int, d_list: int, capacity: int,
+                            threshold: float = 30.0, stream: int | None = None):
+        """Appends the block's hits to the device list at d_list (BOOST_LIST_HEADER_BYTES + 16 * capacity bytes);
+        enqueued on `stream`, not synchronised."""
+        _check(self._L.gw_boost_screen_device(self._h, a_begin, n_a, b_begin, n_b, threshold, d_list, capacity, stream))
+
+    def last_boost_kernel(self) -> str:
+        return self._L.gw_last_boost_kernel(self._h).decode()
+
+    def replicate(self, comm: "GwComm", root: int = 0, stream: int | None = None):
+        _check(self._L.gw_table_replicate(self._h, comm._h, root, stream))
 
     def boost_measures(self, a_begin: int, n_a: int, b_begin: int, n_b: int) -> np.ndarray:
         out = np.zeros((n_a, n_b), dtype=np.float64)

@@ -22,6 +22,8 @@
 // device code (measure, bound, operand expansion) in gw_boost_dev.h.
 #include "gw_boost_dev.h"
 
+#include <cstdio>
+
 namespace gw {
 // ---------------------------------------------------------------------------
 // selectCaseControl: gather the members' bits into dense planes.
@@ -403,7 +405,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err) {
+                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -414,10 +416,24 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.cct = d_cct;
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
-    if (d_cct && d_marf && small_case_group)  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
+    // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)
+    auto note = [&](const char *fmt, const char *x, const char *y) {
+        if (kernel_name) std::snprintf(kernel_name, 96, fmt, x, y);
+    };
+    const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
+    if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
+        note(fast ? "gw::k_boost_mfma_seq<%s, 2, 2, false>" : "gw::k_boost_mfma_seq<%s, 3, 1, false>", tp, "");
         return fast ? launch_boost_mfma_seq4(a, pre, stream) : launch_boost_mfma_seq9(a, pre, stream);
-    if (d_cct && fast) return launch_boost_mfma_both4(a, pre, stream);           // any group size, 2 waves per SIMD
-    if (d_cct && d_marf) return launch_boost_mfma_both9(a, pre, stream);         // any group size, 1 wave per SIMD
+    }
+    if (d_cct && fast) {  // any group size, 2 waves per SIMD
+        note("gw::k_boost_mfma<%s>", tp, "");
+        return launch_boost_mfma_both4(a, pre, stream);
+    }
+    if (d_cct && d_marf) {  // any group size, 1 wave per SIMD
+        note("gw::k_boost_mfma_seq<%s, 3, 1, true>", tp, "");
+        return launch_boost_mfma_both9(a, pre, stream);
+    }
+    note("gw::k_boost<%s, %s>", tfast, tp);
     return launch_boost_valu(a, fast, pre, stream);
 }
 

@@ -53,6 +53,7 @@ struct gw_table {
     gw_geometry geo{};
     int compute_units = 0;
     size_t lds_cap = 0;
+    bool zero_pending = false;  // the table's zero fill has not happened yet (see use_device)
 
     gw::u32x4 *d_case = nullptr, *d_ctrl = nullptr;
     uint32_t case_count = 0, ctrl_count = 0;
@@ -95,7 +96,8 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1;
+    char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
     size_t raw_bytes = 0;
@@ -103,8 +105,18 @@ struct gw_table {
 
 namespace {
 
-int use_device(gw_table *t) {
+// Every entry point that touches the table comes through here.  The zero fill a new table owes its callers
+// ("unknown" everywhere, table5.cpp:82-83) happens at the first such call instead of at create, so that a table
+// which is generated in place (gw_table_simulate overwrites every byte, padding included) never pays for it --
+// 20.7 ms of memset for the 125 GB of config 3.
+int use_device(gw_table *t, bool overwrites_whole_table = false) {
     GW_HIP(hipSetDevice(t->device));
+    if (overwrites_whole_table) t->zero_pending = false;
+    if (t->zero_pending) {
+        t->zero_pending = false;
+        GW_HIP(hipMemsetAsync(t->tv.base, 0, t->geo.device_table_bytes, t->stream));
+        GW_HIP(hipStreamSynchronize(t->stream));  // callers may launch on streams of their own
+    }
     return GW_OK;
 }
 
@@ -112,7 +124,7 @@ hipStream_t pick_stream(gw_table *t, void *s) { return s ? (hipStream_t)s : t->s
 
 // `seg_units` > 0: the shape for one column segment of that many units (row-at-a-time or continuous-stream
 // kernel with both masks in LDS; no single-mask or sub-wave form)
-gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
+gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0, uint64_t n_rows = 0, bool with_stats = true) {
     const uint32_t units = seg_units ? seg_units : t->tv.units;
     // Defaults from the round-1 sweeps on MI355X (profiles/r01_sweep_*.txt):
     //   masks fill more than half the LDS (N > ~320 k): one 256-thread workgroup per CU (one wave per
@@ -165,7 +177,7 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
     // GW_OPT_DEFER_RECORDS: row-at-a-time kernel with both masks in LDS and room for at least one parked group of 64
     // rows per wave beside them (fewer workgroups per CU where that is what it takes)
     const size_t with_park = need + (size_t)(threads / 64) * 1536u;
-    sh.defer = (!seg_units && t->opt_defer && lds && !sh.complement && !sh.pipeline && sh.nontemporal && (unroll == 1 || unroll == 2) &&
+    sh.defer = (!seg_units && t->opt_defer > 0 && lds && !sh.complement && !sh.pipeline && sh.nontemporal && (unroll == 1 || unroll == 2) &&
                 with_park <= t->lds_cap) ? 1 : 0;
     if (sh.defer) per_cu = std::max(1, std::min(per_cu, (int)(t->lds_cap / with_park)));
     sh.grid_blocks = (t->compute_units - sh.reserve_cus) * per_cu;
@@ -180,7 +192,13 @@ gw::ScanShape scan_shape(const gw_table *t, uint32_t seg_units = 0) {
         sh.unroll = 1;
         sh.block_threads = 256;
         sh.grid_blocks = (t->compute_units - sh.reserve_cus) * t->opt_blocks_per_cu;  // 0 = as many as the kernel's registers allow
-        sh.defer = t->opt_defer ? 1 : 0;
+        // Records deferred to the end of the launch (profiles/r03_defer_records_ab.txt): auto = the 16-lane kernels
+        // (N <= 10 k) when one launch's records exceed the 256 MB Infinity Cache -- there the writes between the
+        // reads cost 11 points at N = 10 k (62.5 -> 74.0 % at 4 M SNPs), while records that stay cache-resident
+        // are cheaper written as they are finished (77.6 vs 71.4 % at 1 M SNPs)
+        const uint64_t rows = n_rows ? n_rows : t->tv.n_snps;
+        const uint64_t record_bytes = rows * (uint64_t)(with_stats ? 96u : 32u);
+        sh.defer = t->opt_defer < 0 ? (units <= 80u && record_bytes > (256ull << 20)) : (t->opt_defer ? 1 : 0);
     }
     return sh;
 }
@@ -334,7 +352,7 @@ int gw_table_create(int device, uint32_t n_samples, uint64_t n_snps, gw_table **
     GW_HIP_T(hipEventCreate(&t->ev_stop));
     if (g.device_table_bytes) {
         GW_HIP_T(hipMalloc((void **)&t->tv.base, g.device_table_bytes));
-        GW_HIP_T(hipMemsetAsync(t->tv.base, 0, g.device_table_bytes, t->stream));
+        t->zero_pending = true;  // filled at the first use that does not overwrite the whole table (use_device)
     }
     // masks are zero-padded to a whole number of the widest scan step (8 x 64 units)
     const size_t mask_bytes = (size_t)((t->tv.units + 511u) / 512u) * 512u * 16u;
@@ -588,7 +606,7 @@ int gw_build_stream_mask(const int32_t *idx, size_t n_idx, uint32_t n_samples, u
 int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16) {
     if (!t) return fail(GW_E_INVALID, "NULL table");
     if (missing_q16 > 65535u) return fail(GW_E_INVALID, "missing_q16 must be < 65536");
-    int rc = use_device(t);
+    int rc = use_device(t, true);
     if (rc) return rc;
     t->pending_rows = 0;
     t->selected_valid = false;
@@ -689,7 +707,7 @@ int gw_scan_case_control_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     hipStream_t stream = pick_stream(t, hip_stream);
     const uint32_t seg = column_segment(t);
     if (!seg) {
-        const gw::ScanShape sh = scan_shape(t);
+        const gw::ScanShape sh = scan_shape(t, 0, n_snps, d_stats != nullptr);
         GW_HIP(gw::launch_scan_cc(t->tv, t->d_case, t->d_ctrl, t->case_count, t->ctrl_count, snp_begin,
                                   (uint32_t)n_snps, (uint32_t *)d_counts, (double *)d_stats, sh, stream, nullptr, false,
                                   t->last_scan_kernel));
@@ -744,8 +762,9 @@ int gw_scan_distribution_device(gw_table *t, uint64_t snp_begin, uint64_t n_snps
     if ((rc = use_device(t))) return rc;
     // 512-thread workgroups: one per CU for long rows (few, fat streams), more for short ones
     const int per_cu = t->tv.units <= 256u ? 4 : (t->tv.units < 2000u ? 2 : 1);
-    GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, t->compute_units * per_cu,
-                                pick_stream(t, hip_stream), t->opt_short_rows ? t->compute_units : 0));
+    const int cus = std::max(1, t->compute_units - std::max(t->opt_reserve_cus, 0));  // GW_OPT_RESERVE_CUS
+    GW_HIP(gw::launch_scan_dist(t->tv, snp_begin, (uint32_t)n_snps, (uint32_t *)d_dist, cus * per_cu,
+                                pick_stream(t, hip_stream), t->opt_short_rows ? cus : 0));
     return GW_OK;
 }
 
@@ -966,8 +985,9 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     // FP32 bound first where nobody asked for the extremes: a pair is dropped without its FP64 measure only if
     // bound + err < threshold, err = the bound's own running error bound (gw_boost_dev.h boost_bound).
     // Options 2 / 3 = diagnostic: the dense form returns the bound / its error bound instead of the measure.
+    // (the bound's error model takes float(count) to be exact: cohorts of 2^24 members or more get every pair in FP64)
     const bool diag = dense && t->opt_prefilter >= 2;
-    const bool pre = diag || (!dense && !vmax && !vmin && t->opt_prefilter != 0);
+    const bool pre = diag || (!dense && !vmax && !vmin && t->opt_prefilter != 0 && t->sel_individs < (1u << 24));
     float bound_thr = 0.0f;
     if (pre && !diag) {
         bound_thr = (float)threshold;
@@ -977,7 +997,8 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         return gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
                                 (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, max_hits,
                                 t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
-                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3);
+                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3,
+                                t->last_boost_kernel);
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1006,6 +1027,11 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     if (n_pairs) *n_pairs = tally[1];
     if (vmax) *vmax = tally[1] ? from_ordered(tally[2]) : 0.0;
     if (vmin) *vmin = tally[1] ? from_ordered(tally[3]) : 0.0;
+    // the result buffers stay with the handle for the next block of a walk, but only up to 256 MB each: a one-off
+    // large call (a dense block of 20 k x 20 k measures is 3.2 GB) must not sit next to a 125 GB table for ever
+    const size_t keep = (size_t)256u << 20;
+    if (t->dense_buf_bytes > keep) { (void)hipFree(t->d_dense_buf); t->d_dense_buf = nullptr; t->dense_buf_bytes = 0; }
+    if (t->hits_buf_bytes > keep) { (void)hipFree(t->d_hits_buf); t->d_hits_buf = nullptr; t->hits_buf_bytes = 0; }
     return GW_OK;
 }
 
@@ -1018,6 +1044,99 @@ int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begi
     if (max_hits && !hits) return fail(GW_E_INVALID, "hits is NULL");
     return boost_common(t, a_begin, n_a, b_begin, n_b, threshold, hits, max_hits, n_hits, n_pairs, max_measure,
                         min_measure, nullptr);
+}
+
+// ---- the device-resident form of the screen: hits appended to a caller-owned list in HBM -----------------
+int gw_boost_list_init(gw_table *t, void *d_list, void *hip_stream) {
+    if (!t || !d_list) return fail(GW_E_INVALID, "NULL argument");
+    int rc = use_device(t);
+    if (rc) return rc;
+    // the kernels' tally: hits, pairs, then (pre-filter on) pairs outside the bound's error model / unused,
+    // or (pre-filter off) the ordered maximum / minimum of the measures
+    const bool pre = t->opt_prefilter != 0;
+    const unsigned long long init[4] = {0ull, 0ull, 0ull, pre ? 0ull : ~0ull};
+    GW_HIP(hipMemcpyAsync(d_list, init, sizeof init, hipMemcpyHostToDevice, pick_stream(t, hip_stream)));
+    GW_HIP(hipStreamSynchronize(pick_stream(t, hip_stream)));  // `init` lives on this stack
+    return GW_OK;
+}
+
+int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
+                           void *d_list, uint64_t capacity, void *hip_stream) {
+    static_assert(GW_BOOST_LIST_HEADER_BYTES == 4 * sizeof(unsigned long long), "list header = the kernels' tally");
+    if (!t || !d_list) return fail(GW_E_INVALID, "NULL argument");
+    int rc = check_range(t, a_begin, n_a);
+    if (rc) return rc;
+    if ((rc = check_range(t, b_begin, n_b))) return rc;
+    if (t->tv.n_snps > 0xFFFFFFFFull) return fail(GW_E_RANGE, "pair analysis supports up to 2^32-1 SNPs");
+    if ((rc = ensure_selected(t))) return rc;  // compaction + margins, once per mask / data change (synchronous)
+    if ((rc = use_device(t))) return rc;
+    const bool pre = t->opt_prefilter != 0 && t->sel_individs < (1u << 24);  // as in the host form
+    float bound_thr = 0.0f;
+    if (pre) {
+        bound_thr = (float)threshold;
+        if (!((double)bound_thr <= threshold)) bound_thr = std::nextafter(bound_thr, -INFINITY);
+    }
+    unsigned long long *tally = static_cast<unsigned long long *>(d_list);
+    gw::BoostHit *d_hits = reinterpret_cast<gw::BoostHit *>(static_cast<char *>(d_list) + GW_BOOST_LIST_HEADER_BYTES);
+    GW_HIP(gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
+                            (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, capacity,
+                            tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
+                            t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel));
+    return GW_OK;
+}
+
+// ---- replication of a table's rows over the ranks of a communicator (the pair screen needs every row on every GPU)
+int gw_table_replicate(gw_table *t, gw_comm *c, int root, void *hip_stream) {
+    if (!t || !c) return fail(GW_E_INVALID, "NULL argument");
+    int rc = gw_table_flush(t);
+    if (rc) return rc;
+    if ((rc = use_device(t))) return rc;   // (a receiver's pending zero fill happens here, before the rows land)
+    hipStream_t s = pick_stream(t, hip_stream);
+    if ((rc = gw_comm_broadcast(c, t->tv.base, t->geo.device_table_bytes, root, s))) return rc;
+    // the row header blocks live on the host: through the staging buffer
+    const size_t hb = t->headers.size() * sizeof(uint16_t);
+    if (hb) {
+        void *d_h = nullptr;
+        GW_HIP(hipMalloc(&d_h, hb));
+        hipError_t e = hipMemcpyAsync(d_h, t->headers.data(), hb, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            rc = gw_comm_broadcast(c, d_h, hb, root, s);
+            if (!rc) e = hipMemcpyAsync(t->headers.data(), d_h, hb, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d_h);
+        if (rc) return rc;
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(GW_E_HIP, "gw_table_replicate: %s", hipGetErrorString(e)); }
+    } else {
+        GW_HIP(hipStreamSynchronize(s));
+    }
+    t->selected_valid = false;
+    return GW_OK;
+}
+
+int gw_shard_pair_blocks(uint64_t n_snps, uint32_t block, int rank, int world, uint64_t *a_begin, uint64_t *n_a,
+                         size_t capacity, size_t *n_blocks) {
+    if (!n_blocks || ((!a_begin || !n_a) && capacity)) return fail(GW_E_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GW_E_INVALID, "rank %d outside a world of %d", rank, world);
+    if (block == 0) return fail(GW_E_INVALID, "block must be > 0");
+    // row blocks dealt in snake order 0 .. W-1, W-1 .. 0, ...: block k holds ~ block x (n - k block) pairs, the
+    // snake balances the triangle to well under 1 % (libgwaspp_amd/shard.py pair_row_blocks is the same cut)
+    const uint64_t total = (n_snps + block - 1u) / block;
+    size_t n = 0;
+    for (uint64_t k = 0; k < total; ++k) {
+        const uint64_t rnd = k / (uint64_t)world, pos = k % (uint64_t)world;
+        const uint64_t owner = (rnd % 2u == 0u) ? pos : (uint64_t)world - 1u - pos;
+        if (owner != (uint64_t)rank) continue;
+        const uint64_t a = k * block, len = std::min<uint64_t>(block, n_snps - a);
+        if (n && n <= capacity && a_begin[n - 1] + n_a[n - 1] == a) {  // adjacent row blocks: one launch
+            n_a[n - 1] += len;
+            continue;
+        }
+        if (n < capacity) { a_begin[n] = a; n_a[n] = len; }
+        ++n;
+    }
+    *n_blocks = n;
+    return GW_OK;
 }
 
 int gw_boost_measures(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double *measures) {
@@ -1124,6 +1243,7 @@ int gw_stream_read_probe(gw_table *t, void *hip_stream, uint64_t *bytes_read) {
 }
 
 const char *gw_last_scan_kernel(const gw_table *t) { return t ? t->last_scan_kernel : ""; }
+const char *gw_last_boost_kernel(const gw_table *t) { return t ? t->last_boost_kernel : ""; }
 
 int gw_table_stream(gw_table *t, void **hip_stream) {
     if (!t || !hip_stream) return fail(GW_E_INVALID, "NULL argument");
@@ -1176,7 +1296,8 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_boost_mfma = (int)v;
         return GW_OK;
     case GW_OPT_DEFER_RECORDS:
-        t->opt_defer = v ? 1 : 0;
+        if (v < -1 || v > 1) return fail(GW_E_INVALID, "defer_records must be -1 (auto), 0 or 1");
+        t->opt_defer = (int)v;
         return GW_OK;
     case GW_OPT_SHORT_ROWS:
         t->opt_short_rows = v ? 1 : 0;

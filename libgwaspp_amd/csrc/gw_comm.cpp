@@ -11,10 +11,12 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/gwas_scan.h"
 
@@ -40,6 +42,8 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string why;
 };
@@ -48,13 +52,19 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, []() {
-        // a process that already holds an RCCL (torch ships its own librccl.so) keeps using that one: same SONAME
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // a process that already holds an RCCL (torch ships its own librccl.so) keeps using that one: same SONAME.
+        // GW_RCCL_LIBRARY names the one file to load instead (deployments with RCCL elsewhere; the loader's own test)
+        std::vector<std::string> names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (const char *only = std::getenv("GW_RCCL_LIBRARY")) names.assign(1, only);
+        std::string tried;
+        for (const std::string &name : names) {
+            r.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            const char *e = dlerror();  // read once: the call clears the message
+            tried += (tried.empty() ? "" : "; ") + name + ": " + (e ? e : "?");
         }
         if (!r.lib) {
-            r.why = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "?");
+            r.why = "librccl not loadable (" + tried + ")";
             return;
         }
 #define GW_SYM(field, sym)                                                        \
@@ -67,6 +77,8 @@ Rccl &rccl() {
         GW_SYM(GroupEnd, ncclGroupEnd)
         GW_SYM(Send, ncclSend)
         GW_SYM(Recv, ncclRecv)
+        GW_SYM(AllGather, ncclAllGather)
+        GW_SYM(Broadcast, ncclBroadcast)
         GW_SYM(GetErrorString, ncclGetErrorString)
 #undef GW_SYM
     });
@@ -197,6 +209,29 @@ int gw_comm_gather(gw_comm *c, const void *d_send, size_t bytes, void *d_recv, i
     return GW_OK;
 }
 
+int gw_comm_allgather(gw_comm *c, const void *d_send, size_t bytes, void *d_recv, void *hip_stream) {
+    if (!c || ((!d_send || !d_recv) && bytes)) return fail(GW_E_INVALID, "NULL argument");
+    if (bytes == 0) return GW_OK;
+    GW_HIPC(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->world == 1) {  // nothing to exchange: the own slice is the whole result
+        if (d_recv != d_send) GW_HIPC(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));
+        return GW_OK;
+    }
+    GW_NCCL(rccl().AllGather(d_send, d_recv, bytes, ncclUint8, c->comm, s));
+    return GW_OK;
+}
+
+int gw_comm_broadcast(gw_comm *c, void *d_buf, size_t bytes, int root, void *hip_stream) {
+    if (!c || (!d_buf && bytes)) return fail(GW_E_INVALID, "NULL argument");
+    if (root < 0 || root >= c->world) return fail(GW_E_INVALID, "root %d outside a world of %d", root, c->world);
+    if (bytes == 0 || c->world == 1) return GW_OK;
+    GW_HIPC(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    GW_NCCL(rccl().Broadcast(d_buf, d_buf, bytes, ncclUint8, root, c->comm, s));
+    return GW_OK;
+}
+
 int gw_comm_synchronize(gw_comm *c, void *hip_stream) {
     if (!c) return fail(GW_E_INVALID, "NULL comm");
     GW_HIPC(hipSetDevice(c->device));
@@ -217,6 +252,13 @@ int gw_device_free(int device, void *d_ptr) {
     if (!d_ptr) return GW_OK;
     GW_HIPC(hipSetDevice(device));
     GW_HIPC(hipFree(d_ptr));
+    return GW_OK;
+}
+
+int gw_device_memset(int device, void *d_ptr, int value, size_t bytes, void *hip_stream) {
+    if (!d_ptr && bytes) return fail(GW_E_INVALID, "NULL argument");
+    GW_HIPC(hipSetDevice(device));
+    if (bytes) GW_HIPC(hipMemsetAsync(d_ptr, value, bytes, (hipStream_t)hip_stream));
     return GW_OK;
 }
 

@@ -143,7 +143,9 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         // force the kernels that keep both groups' accumulators (what case groups >= 65 536 get)
                         bool both_groups = false,
                         // diagnostic (prefilter + d_dense): write the bound's error bound instead of the bound
-                        bool dense_err = false);
+                        bool dense_err = false,
+                        // char[96] or null: the kernel instantiation the launch went to, as rocprofv3 prints it
+                        char *kernel_name = nullptr);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

@@ -1064,12 +1064,15 @@ __global__ void __launch_bounds__(256) k_scan_dist_sub(const u32x4 *table, uint6
 template <int G, int STEPS>
 static hipError_t launch_scan_dist_sub(const TableView &tv, uint64_t row_begin, uint32_t n_rows, uint32_t *d_dist,
                                        int compute_units, hipStream_t stream) {
-    static int resident = 0;
-    if (!resident) {
+    static int per_device[16] = {0};  // workgroups a CU holds (registers; <= 8), per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!per_device[dev]) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_dist_sub<G, STEPS>, 256, 0) != hipSuccess || n < 1) n = 2;
-        resident = n > 8 ? 8 : n;
+        per_device[dev] = n > 8 ? 8 : n;
     }
+    const int resident = per_device[dev];
     hipLaunchKernelGGL((k_scan_dist_sub<G, STEPS>), dim3(compute_units * resident), dim3(256), 0, stream, tv.base,
                        tv.row_stride_u, tv.plane_stride_u, tv.units, tv.n_samples, row_begin, n_rows, d_dist);
     return hipGetLastError();
@@ -1105,9 +1108,8 @@ hipError_t launch_scan_dist(const TableView &tv, uint64_t row_begin, uint32_t n_
 }
 
 // ---------------------------------------------------------------------------
-// pairwise 4x4 contingency for a list of SNP pairs: one wave per pair.
-// (first correct form; the LDS-tiled all-pairs kernel of BASELINE config 5 is
-// the NEXT row)
+// pairwise 4x4 contingency for a LIST of SNP pairs: one wave per pair (the getters of
+// PairwiseMarkerAnalyzable; the all-pairs screen of BASELINE config 5 is gw_boost*.hip)
 // ---------------------------------------------------------------------------
 // classes of one 32-bit word: [aa, ab, bb, xx] (DecodeBitStreams2BitStream,
 // compressed_genotype_table5.h:104-115)

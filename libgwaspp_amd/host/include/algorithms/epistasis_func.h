@@ -29,6 +29,10 @@ void computeMargins(GenoTable &gt, int nIndivids, marginal_information *&pMargin
 // the pairs that passed; prints the reference's report
 void computeBoost(GeneticData *gd, std::ostream *out);
 
+// the second half of computeBoost (:488-505): "Located ...", computeGTest on the passing pairs, the report lines
+void boostStage2AndReport(GenoTable &gt, marginal_information *pMargins, int nIndivids,
+                          std::vector<SNPInteractionPair> &passingThreshold, std::ostream *out);
+
 // stage 2: iterative proportional fit + exact measure + odds-ratio z per listed
 // pair; passingThreshold[k].second is replaced by the exact measure
 void computeGTest(GenoTable &gt, marginal_information *pMargins, uint nIndivids,

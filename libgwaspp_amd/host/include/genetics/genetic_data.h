@@ -28,6 +28,9 @@ public:
 
     void createGenotypedIndividuals(const std::vector<std::string> &ids);
     void createGenotypedMarkers(const std::vector<std::string> &ids);
+    // n entries named by their ordinal (tables generated in place: gwas_hip --simulate)
+    void createGenotypedIndividuals(int n);
+    void createGenotypedMarkers(int n);
     int getGenotypedIndividualsCount() const { return genotyped_individs ? genotyped_individs->included_size() : 0; }
     int getGenotypedMarkersCount() const { return genotyped_markers ? genotyped_markers->included_size() : 0; }
     int getGenotypedIndividualIndex(const std::string &id) const { return genotyped_individs->orderOf(id); }
@@ -44,6 +47,8 @@ public:
 
     // genetic_data.cpp:116-158: ids -> column indices; an id in both sets stays a case
     void setCaseControlSet(std::set<std::string> *case_set, std::set<std::string> *ctrl_set);
+    // the same from column indices
+    void setCaseControlColumns(const std::set<int> &cases, const std::set<int> &controls);
     CaseControlSet *getCaseControlSet() { return ccs; }
 
 private:

@@ -27,6 +27,7 @@
 
 struct gw_table;  // include/gwas_scan.h
 struct gw_marginal_information;
+struct gw_comm;
 
 namespace libgwaspp {
 namespace genetics {
@@ -92,6 +93,10 @@ public:
     // all bytes on every getter call (N/4 bytes of host reads per call)
     void setMaskCheckEveryCall(bool on) { check_every_call = on; }
     gw_table *handle() { settle(); return tbl; }
+    // the rows were changed through handle() (gw_table_simulate, gw_table_upload_rows): drop every host cache
+    void tableChanged() { invalidate(); }
+    // the rows of rank `root`'s table into this one (gw_table_replicate: one RCCL broadcast), caches dropped
+    void replicateFrom(gw_comm *comm, int root);
 
 protected:
     void initialize() override;

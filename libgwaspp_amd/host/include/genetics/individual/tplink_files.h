@@ -17,9 +17,10 @@ bool readTfamIndividuals(const std::string &tfam, GeneticData *gd);
 // marker ids (column 2) of every .tped line; creates the table, then packs
 // every genotype row through GenoTable::addGenotypeRow
 // (first_marker, n_markers: only that range of the file's lines becomes the table -- a rank's shard of a job;
-// n_markers < 0 = to the end)
+// n_markers < 0 = to the end; ids_only: the table is created with the markers' rows left empty -- a rank that
+// receives the rows from another one, gw_table_replicate)
 bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim = '\t', long first_marker = 0,
-                       long n_markers = -1);
+                       long n_markers = -1, bool ids_only = false);
 // number of marker lines in a .tped (the job's n_total when it is sharded)
 long countTpedMarkers(const std::string &tped);
 // sixth .tfam column: '1' case, '0' control, anything else neither

@@ -177,6 +177,13 @@ void computeBoost(GeneticData *gd, std::ostream *out) {
             }
     }
     *out << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << std::endl;
+    boostStage2AndReport(gt, pMargins, nIndivids, passingThreshold, out);
+    delete[] pMargins;
+}
+
+void boostStage2AndReport(GenoTable &gt, marginal_information *pMargins, int nIndivids,
+                          std::vector<SNPInteractionPair> &passingThreshold, std::ostream *out) {
+    const double thresholdRecord = 30.0;  // :390
     *out << "Located " << passingThreshold.size() << " potential interactions" << std::endl;
     *out << "Performing deeper analysis of SNPs" << std::endl;
 
@@ -192,7 +199,6 @@ void computeBoost(GeneticData *gd, std::ostream *out) {
             *out << line << std::endl;
         }
     }
-    delete[] pMargins;
 }
 
 void ContingencyPerformance(GeneticData *gd, std::ostream *out) {

@@ -31,6 +31,25 @@ void GeneticData::createGenotypedMarkers(const std::vector<std::string> &ids) {
     genotyped_markers = new util::SequentialIndexer(ids);
 }
 
+void GeneticData::createGenotypedIndividuals(int n) {
+    delete genotyped_individs;
+    genotyped_individs = new util::SequentialIndexer(n);
+}
+
+void GeneticData::createGenotypedMarkers(int n) {
+    delete genotyped_markers;
+    genotyped_markers = new util::SequentialIndexer(n);
+}
+
+void GeneticData::setCaseControlColumns(const std::set<int> &cases, const std::set<int> &controls) {
+    if (!ccs) ccs = new CaseControlSet(genotyped_individs);
+    ccs->reset();
+    std::set<int> ctrl_only(controls);
+    for (int i : cases) ctrl_only.erase(i);  // a column in both sets stays a case (genetic_data.cpp:148-153)
+    ccs->setCases(cases);
+    ccs->setControls(ctrl_only);
+}
+
 void GeneticData::updateGenotypeTable() {
     delete geno_tbl;
     geno_tbl = nullptr;

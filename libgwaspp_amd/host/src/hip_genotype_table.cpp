@@ -68,6 +68,12 @@ HipGenotypeTable::~HipGenotypeTable() {
     gw_table_destroy(tbl);
 }
 
+void HipGenotypeTable::replicateFrom(gw_comm *comm, int root) {
+    drop_prefetch();
+    die_unless_ok(gw_table_replicate(tbl, comm, root, nullptr), "gw_table_replicate");
+    invalidate();
+}
+
 void HipGenotypeTable::invalidate() {
     drop_prefetch();
     run.valid = false;

@@ -42,7 +42,8 @@ long countTpedMarkers(const std::string &tped) {
     return n;
 }
 
-bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim, long first_marker, long n_markers) {
+bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim, long first_marker, long n_markers,
+                       bool ids_only) {
     std::ifstream in(tped.c_str());
     if (!in.is_open()) return false;
     const long last_marker = n_markers < 0 ? -1 : first_marker + n_markers;  // exclusive; -1 = to the end
@@ -60,6 +61,7 @@ bool readTpedGenotypes(const std::string &tped, GeneticData *gd, char delim, lon
     }
     gd->createGenotypedMarkers(markers);
     gd->updateGenotypeTable();
+    if (ids_only) return true;  // the rows arrive some other way (gw_table_replicate from the rank that read them)
     // pass 2: genotype rows (parseNextGenotypeRecord, :127-190), a batch of lines at a time: the
     // lines are normalised ("A C A A ..." -> "AC<d>AA<d>...", 1..4 -> ACGT) by all host cores and
     // handed to the table together

@@ -281,3 +281,32 @@ def test_epistasis_performance_harness(oracle):
         got = line[line.index("(") + 1:line.index(")")].split(", ")
         assert got[0] == f"{m * (m - 1) // 2} pairs" and got[1] == f"{undefined} undefined"
         assert float(got[2].split()[-1]) == pytest.approx(total, rel=1e-8)
+
+
+# ---- the drop-in table on tables generated in HBM (gwas_hip --simulate) ------------------------------------------
+def _simulate(args, mode):
+    return subprocess.run([CLI, "--simulate"] + [str(a) for a in args] + [mode], capture_output=True, text=True, timeout=600)
+
+
+def test_inline_cc_maf_walk_over_a_simulated_table_equals_the_batch_scan():
+    """gwas_hip --simulate N M --time-inline-cc-maf: the reference's harness loop (maf_func.cpp:292-316) walking the per-row
+    getter of HipGenotypeTable over every row, window prefetch on and off, counts equal to one batch scan; one JSON line."""
+    import json
+    r = _simulate([10_000, 30_000, "--scan-window", "4096", "--missing-q16", "655"], "--time-inline-cc-maf")
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["walk_equals_batch_scan"] is True and d["n_snps"] == 30_000 and d["n_samples"] == 10_000
+    assert d["snps_per_s_prefetch"] > 0 and d["snps_per_s_no_prefetch"] > 0 and d["kernel_snps_per_s"] > d["snps_per_s_prefetch"]
+    assert d["kernel"].startswith("gw::k_scan_cc_sub<16, 5, true")
+
+
+@pytest.mark.parametrize("extra", [[], ["--mask-check-every-call"]])
+def test_case_control_set_edited_in_place_reaches_the_device(extra):
+    """The reference's CaseControlSet has no change counter (case_control_set.h:48-91): an edit that keeps the object and
+    both counts must still be noticed -- by the next window of rows and by selectCaseControl (every byte compared), or by
+    the very next getter call with setMaskCheckEveryCall."""
+    r = _simulate([3000, 500, "--scan-window", "64"] + extra, "--mask-edit-selftest")
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("PASS", "FAIL"))]
+    assert lines and all(ln.startswith("PASS") for ln in lines), lines
+    assert len(lines) == (2 if extra else 3)

@@ -43,11 +43,15 @@ SHAPES = [  # (n_samples, n_snps, options, kernel of the two-mask scan, kernel o
     (3_000, 700, {}, "gw::k_scan_cc_sub<16, ", "gw::k_scan_cc_sub<16, "),
     (24_000, 300, {}, "gw::k_scan_cc_sub<32, ", "gw::k_scan_cc_sub<32, "),
     (24_000, 300, {capi.OPT_SHORT_ROWS: 0}, "gw::k_scan_cc<", "gw::k_scan_cc<"),
-    (90_000, 150, {}, "gw::k_scan_cc<1, true, true>", "gw::k_scan_cc<1, true, true>"),
+    (90_000, 150, {}, "gw::k_scan_cc<1, true, true, false>", "gw::k_scan_cc<1, true, true, false>"),
+    # records deferred to the end of the launch (GW_OPT_DEFER_RECORDS): sub-wave kernels and the row-at-a-time kernel
+    (3_000, 700, {capi.OPT_DEFER_RECORDS: 1}, "gw::k_scan_cc_sub<16, 2, true, true>", "gw::k_scan_cc_sub<16, 2, true, true>"),
+    (24_000, 300, {capi.OPT_DEFER_RECORDS: 1}, "gw::k_scan_cc_sub<32, 6, true, true>", "gw::k_scan_cc_sub<32, 6, true, true>"),
+    (90_000, 150, {capi.OPT_DEFER_RECORDS: 1}, "gw::k_scan_cc<1, true, true, true>", "gw::k_scan_cc<1, true, true, true>"),
     (90_000, 150, {capi.OPT_PIPELINE: 1}, "gw::k_scan_cc_pipe<", "gw::k_scan_cc_pipe<"),
     (90_000, 150, {capi.OPT_COMPLEMENT: 2}, "gw::k_scan_cc<", "gw::k_scan_cc_compl<"),   # single mask where the phenotype allows
     (90_000, 150, {capi.OPT_COLUMN_SEGMENT: 128}, "gw::k_scan_cc", "gw::k_scan_cc"),     # column segments
-    (90_000, 150, {capi.OPT_MASK_IN_LDS: 0}, "gw::k_scan_cc<4, false, true>", "gw::k_scan_cc<4, false, true>"),
+    (90_000, 150, {capi.OPT_MASK_IN_LDS: 0}, "gw::k_scan_cc<4, false, true, false>", "gw::k_scan_cc<4, false, true, false>"),
 ]
 
 

@@ -540,3 +540,52 @@ def test_scan_with_masks_from_the_real_reference_object(oracle, n, m):
         assert tuple(int(v) for v in counts[r]) == want
         _assert_stats(stats[r], oracle.assoc_stats(want[:4], want[4:]))
 
+
+
+# --------------------------------------------------------------------------
+# GW_OPT_DEFER_RECORDS: the same records whether they are written as rows finish or in one burst at the end of the
+# launch, also when a call is cut into several launches (each piece's parking area is a few KB of LDS per wave) and
+# when the last 64-row group of a wave is partial
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,missing", [(2_000, 3_400_003, 655), (9_999, 300_000, 0), (20_000, 70_001, 655),
+                                         (70_000, 40_000, 655), (100_000, 9_000, 0), (1_000, 37, 655)])
+def test_deferred_records_equal_interleaved_records(oracle, n, m, missing):
+    with gw.GwTable(n, m) as t:
+        t.simulate(0xD1FE, 5, missing)
+        t.simulate_phenotype(0xD1FE)
+        t.set_option(capi.OPT_DEFER_RECORDS, 0)
+        c0, s0 = t.scan_case_control()
+        k0 = t.last_scan_kernel()
+        t.set_option(capi.OPT_DEFER_RECORDS, 1)
+        assert t.get_option(capi.OPT_DEFER_RECORDS) == 1
+        c1, s1 = t.scan_case_control()
+        k1 = t.last_scan_kernel()
+        assert k0.endswith("false>") and k1.endswith("true>") and k0[:-6] == k1[:-5], (k0, k1)
+        assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+        lo, cnt = m // 7, m - m // 7 - 3                       # a sub-range is a slice, counts-only too
+        c2, s2 = t.scan_case_control(lo, cnt)
+        assert np.array_equal(c2, c0[lo:lo + cnt]) and np.array_equal(s2, s0[lo:lo + cnt])
+        # and the oracle on a few rows spread over the pieces
+        rows_at = sorted({0, 1, m // 3, m // 2, m - 2, m - 1})
+        cs, ct, nc, nt = t.get_case_control()
+        g = oracle.geometry_stream(n)
+        for r in rows_at:
+            row = t.download_rows(r, 1)
+            want_c, want_s = oracle.scan_stream_cc(row, g, cs, ct, nc, nt)
+            assert np.array_equal(c1[r], want_c[0])
+            _assert_stats(s1[r], want_s[0])
+
+
+def test_deferred_records_auto_policy():
+    """auto: the 16-lane kernels when one call's records exceed the 256 MB Infinity Cache (3 M SNPs x 96 B)."""
+    with gw.GwTable(2_000, 3_000_000) as t:
+        t.simulate(1, 0, 0)
+        t.simulate_phenotype(1)
+        assert t.get_option(capi.OPT_DEFER_RECORDS) == 1
+        c, s = t.scan_case_control()
+        assert t.last_scan_kernel() == "gw::k_scan_cc_sub<16, 1, true, true>"
+        c_small, s_small = t.scan_case_control(1000, 50_000)          # a small call: interleaved form
+        assert t.last_scan_kernel() == "gw::k_scan_cc_sub<16, 1, true, false>"
+        assert np.array_equal(c_small, c[1000:51_000]) and np.array_equal(s_small, s[1000:51_000])
+    with gw.GwTable(2_000, 100_000) as t:
+        assert t.get_option(capi.OPT_DEFER_RECORDS) == 0

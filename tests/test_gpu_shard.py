@@ -217,3 +217,57 @@ def test_bench_exchange_through_torch_rccl_with_one_rank():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["dist_with_one_rank"] == {"backend": "nccl", "gathered_equals_scanned": True}
     assert "torch.distributed gather (RCCL)" in line["config"]["exchange"]
+
+
+# ---- config 5: the pair screen sharded over ranks (SURVEY.md 8e "C5") ---------------------------------------------
+def test_bench_c5_two_ranks_rehearsed_on_one_gpu():
+    """bench.py --workload c5 with two ranks on device 0 (gloo): each rank screens the row blocks gw_shard_pair_blocks
+    deals it, hits go to a device list (gw_boost_screen_device), the lists are all-gathered; rank 0 requires the union
+    of the two lists to be the single-process screen of the whole triangle, measures bit-identical."""
+    r = _torchrun(["--workload", "c5", "--rehearse-on-one-gpu", "--snps", "6000", "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "pairs/s"
+    assert line["config"]["pairs"] == 6000 * 5999 // 2
+    assert line["config"]["rehearsal_union_equals_single_screen"] is True
+    assert line["config"]["hits_over_30"] > 0
+    assert line["roofline"]["kernel"].startswith("gw::k_boost_mfma_seq<true, 2, 2")
+
+
+def test_bench_c5_exchange_through_the_c_abi_on_one_gpu():
+    """--exchange capi at N = 1: gw_comm_allgather (a world of one copies) behind the screens on the same stream."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--snps", "5000", "--exchange", "capi",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["exchange"].startswith("gw_comm_allgather")
+    assert line["config"]["pairs"] == 5000 * 4999 // 2 and line["config"]["hits_over_30"] > 0
+
+
+def test_cpp_host_sharded_boost_with_one_rank(tmp_path):
+    """gwas_hip --test-boost-epi --world 1: computeBoostSharded (gw_comm_create, gw_table_replicate, gw_shard_pair_blocks,
+    gw_boost_screen_device, gw_comm_allgather, stage 2 on rank 0) prints the report lines of the plain computeBoost."""
+    import numpy as np
+    cli = os.path.join(ROOT, "libgwaspp_amd", "bin", "gwas_hip")
+    n, m = 2000, 60
+    rng = np.random.default_rng(5)
+    status = rng.integers(0, 2, size=n)
+    q = rng.uniform(0.1, 0.5, size=(m, 1))
+    a = (rng.random((m, n)) < q).astype(np.uint8) + (rng.random((m, n)) < q).astype(np.uint8)
+    for i, j in ((3, 17), (20, 31), (40, 59)):
+        copy = (status == 1) & (rng.random(n) < 0.7)
+        a[j, copy] = a[i, copy]
+    sym = np.array(["A A", "A C", "C C"])
+    with open(tmp_path / "d.tped", "w") as f:
+        for r in range(m):
+            f.write(f"0 rs{r} 0 {r} " + " ".join(sym[a[r]]) + "\n")
+    with open(tmp_path / "d.tfam", "w") as f:
+        for s in range(n):
+            f.write(f"Fam_{s} Ind_{s} Pat_{s} Mat_{s} x {status[s]}\n")
+    base = [cli, "-g", str(tmp_path / "d.tped"), "-p", str(tmp_path / "d.tfam")]
+    plain = subprocess.run(base + ["--test-boost-epi"], check=True, capture_output=True, text=True).stdout
+    shard = subprocess.run(base + ["--world", "1", "--rank", "0", "--comm-id", str(tmp_path / "id"), "--comm-nonce", "77",
+                                   "--test-boost-epi"], check=True, capture_output=True, text=True).stdout
+    keep = lambda text: [ln for ln in text.splitlines() if ln.count("\t") == 6 or ln.startswith("Located ")]
+    assert len(keep(plain)) >= 4 and keep(shard) == keep(plain)

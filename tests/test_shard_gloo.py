@@ -132,3 +132,44 @@ def test_c_abi_shard_range_equals_the_python_partition():
                 assert gw.shard_range(total, r, world) == shard.snp_range(total, r, world)
     with pytest.raises(gw.GwError):
         gw.shard_range(10, 2, 2)
+
+
+def test_c_abi_pair_blocks_equal_the_python_partition():
+    """gw_shard_pair_blocks (host-only) deals the row blocks of the pair triangle exactly as shard.pair_row_blocks does,
+    adjacent blocks merged; every rank's share covers the triangle once."""
+    import libgwaspp_amd as gw
+    from libgwaspp_amd import shard
+    for n in (0, 1, 7, 1000, 4097, 100_000):
+        for world in (1, 2, 3, 8):
+            pairs = 0
+            for r in range(world):
+                merged = []
+                for a, na in sorted(shard.pair_row_blocks(n, r, world, block=512)):
+                    if merged and merged[-1][0] + merged[-1][1] == a:
+                        merged[-1] = (merged[-1][0], merged[-1][1] + na)
+                    else:
+                        merged.append((a, na))
+                got = gw.shard_pair_blocks(n, r, world, 512)
+                assert got == merged, (n, world, r)
+                pairs += sum(na * (n - a) - na * (na + 1) // 2 for a, na in got)
+            assert pairs == n * (n - 1) // 2
+    with pytest.raises(gw.GwError):
+        gw.shard_pair_blocks(10, 2, 2)
+
+
+def test_missing_rccl_is_an_error_with_a_message_not_a_crash():
+    """librccl is loaded at run time; when it cannot be, gw_comm_new_id / gw_comm_create return GW_E_HIP and
+    gw_last_error() names every file tried (round 2 crashed here on a NULL dlerror())."""
+    import subprocess
+    import sys
+    code = ("import libgwaspp_amd as gw\n"
+            "for f in (gw.comm_new_id, lambda: gw.GwComm(0, 0, 1, bytes(128))):\n"
+            "    try:\n"
+            "        f(); raise SystemExit('no error')\n"
+            "    except gw.GwError as e:\n"
+            "        assert e.code == -2 and 'librccl not loadable' in str(e) and '/nonexistent/librccl.so' in str(e), str(e)\n"
+            "print('ok')\n")
+    env = dict(os.environ, GW_RCCL_LIBRARY="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
