@@ -267,8 +267,32 @@ def side_workload(name, steps, warmup):
             t.scan_case_control_device(0, m, base, base + m * 32, None)
         ms = t.timer_stop(None) / steps
         gbps = m * (n / 4.0) / (ms * 1e-3) / 1e9
+        kernel = t.last_scan_kernel()
+        traffic, traffic_note = pmc_traffic(name, kernel)
         return {"workload": text, "ms_per_step": ms, "value": m / (ms * 1e-3), "unit": "SNPs/s",
-                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "kernel": t.last_scan_kernel()}
+                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "kernel": kernel,
+                "algorithmic_bytes_per_launch": m * (n / 4.0), "traffic": traffic, "traffic_source": traffic_note}
+
+
+def dropin_walk(name):
+    """What a libgwaspp maintainer gets: the reference's own harness loop inline_cc_maf (algorithms/maf_func.cpp:292-316)
+    walking HipGenotypeTable's per-row getter over a table of the workload's shape generated in HBM
+    (libgwaspp_amd/bin/gwas_hip --simulate N M --time-inline-cc-maf, the C++ host over the C-ABI), window prefetch on
+    and off, beside the kernel rate of the same table; the walk's counts are checked against one batch scan."""
+    n, m, text = WORKLOADS[name]
+    cli = os.path.join(ROOT, "libgwaspp_amd", "bin", "gwas_hip")
+    if not os.path.exists(cli):
+        return {"workload": text, "error": "libgwaspp_amd/bin/gwas_hip is not built (make -C libgwaspp_amd/host)"}
+    r = subprocess.run([cli, "--simulate", str(n), str(m), "--seed", str(SEED), "--time-inline-cc-maf"], capture_output=True,
+                       text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"workload": text, "error": f"gwas_hip exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+    d = json.loads(line[-1])
+    d["workload"] = text
+    d["value"], d["unit"] = d["snps_per_s_prefetch"], "SNPs/s"
+    d["walk_over_kernel"] = d["snps_per_s_prefetch"] / d["kernel_snps_per_s"]
+    return d
 
 
 def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, with_cpu_baseline=True, comm=None):
@@ -744,7 +768,8 @@ def main():
             out["cpu_baseline"]["c1"] = cpu_baseline_c1()
         if not args.no_extra:
             extra = {"c2": side_workload("c2", args.steps, args.warmup),
-                     "n10k": side_workload("n10k", args.steps, args.warmup)}
+                     "n10k": side_workload("n10k", args.steps, args.warmup),
+                     "dropin_walk_c2": dropin_walk("c2")}
             c5 = bench_pairs(args, 0, 1, local_rank, None, steps=3, warmup=1, with_cpu_baseline=not args.no_cpu_baseline)
             extra["c5"] = {"workload": c5["config"]["workload"], "ms_per_step": c5["ms_per_step"],
                            "value": c5["value"], "unit": c5["unit"], "pairs": c5["config"]["pairs"],

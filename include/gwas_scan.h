@@ -379,6 +379,10 @@ typedef enum gw_option {
                                 gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
                                 512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
                                 scan workgroup that has to wait for one finishes its static share of the rows late */
+    GW_OPT_BOOST_STAGGER_US = 16, /* pair screen, one-group-at-a-time MFMA kernels: microseconds the workgroups in odd wave
+                                slots of the FIRST generation wait before they start, so that the two workgroups of a
+                                CU are out of step from then on (one's per-pair evaluation on the vector ALU runs under the
+                                other's counting on the matrix cores).  -1 (default) auto, 0 off; get returns the value in use */
     GW_OPT_DEFER_RECORDS = 15, /* rows up to ~100 k samples: 1 = nothing is written while the table is being read; a wave
                                 parks the six sums of its finished rows in LDS and, after its last row, runs the FP64
                                 epilogue over all of them and writes its records in one burst (launches are cut

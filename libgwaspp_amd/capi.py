@@ -32,6 +32,7 @@ OPT_COLUMN_SEGMENT = 11
 OPT_BOOST_PREFILTER_TRIPS = 12
 OPT_RESERVE_CUS = 14
 OPT_DEFER_RECORDS = 15
+OPT_BOOST_STAGGER_US = 16
 
 
 class GwError(RuntimeError):

@@ -405,7 +405,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name) {
+                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name,
+                        unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -414,6 +415,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
     a.marf = d_marf; a.bound_threshold = bound_threshold; a.dense_err = dense_err ? 1 : 0;
     a.cct = d_cct;
+    a.ticket = nullptr; a.first_gen = 0; a.stagger_ticks = 0;
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
     // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)
@@ -422,6 +424,11 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     };
     const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
     if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
+        if (d_ticket && stagger_ticks && !d_dense) {
+            hipError_t e = hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
+            if (e != hipSuccess) return e;
+            a.ticket = d_ticket; a.first_gen = first_gen; a.stagger_ticks = stagger_ticks;
+        }
         note(fast ? "gw::k_boost_mfma_seq<%s, 2, 2, false>" : "gw::k_boost_mfma_seq<%s, 3, 1, false>", tp, "");
         return fast ? launch_boost_mfma_seq4(a, pre, stream) : launch_boost_mfma_seq9(a, pre, stream);
     }

@@ -133,7 +133,31 @@ struct BoostArgs {
     const SnpMarginF *marf;     // PRE only
     const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
     float bound_threshold;      // PRE: the threshold rounded down to float; bound + err < this rules a pair out
+    // Start-up stagger of the one-group-at-a-time MFMA kernels: a workgroup's life is a matrix-core phase (counting)
+    // followed by a vector-ALU phase (the per-pair bound / measure), and the two workgroups a CU holds start
+    // together and stay in step -- both count, then both evaluate, the matrix cores idle meanwhile.  The
+    // workgroups of the first generation (ticket < first_gen) that sit in an odd wave slot wait stagger_ticks of
+    // the 100 MHz clock before they start, once; from then on one workgroup's evaluation runs under the
+    // other's counting.  ticket: a device counter zeroed before the launch; null / 0 = no stagger.
+    unsigned int *ticket;
+    uint32_t first_gen, stagger_ticks;
 };
+
+// (see BoostArgs::ticket) called by every thread of a workgroup that has work, before it starts
+__device__ __forceinline__ void boost_stagger(const BoostArgs &a, uint32_t *s_flag) {
+    if (!a.ticket || !a.stagger_ticks) return;
+    if (threadIdx.x == 0) {
+        const uint32_t tk = atomicAdd(a.ticket, 1u);
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        *s_flag = (tk < a.first_gen && (hw_id & 1u)) ? 1u : 0u;   // HW_ID[3:0] = the wave's slot on its SIMD
+    }
+    __syncthreads();
+    if (*s_flag) {
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
+}
 
 
 // ---- operand expansion of the int8 MFMA kernels

@@ -96,7 +96,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1;
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -865,7 +865,7 @@ int ensure_selected(gw_table *t) {
         if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
         if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
     }
-    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long)));
+    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 6 * sizeof(unsigned long long)));  // [4]: launch ticket counter
     if (m) {
         if (!t->d_cc) GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
         if (!t->d_mar) GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
@@ -942,6 +942,13 @@ double from_ordered(unsigned long long u) {
     return d;
 }
 
+// GW_OPT_BOOST_STAGGER_US: -1 auto, 0 off, > 0 microseconds
+uint32_t boost_stagger_ticks(const gw_table *t) {
+    if (t->opt_boost_stagger == 0) return 0;
+    if (t->opt_boost_stagger > 0) return (uint32_t)t->opt_boost_stagger * 100u;
+    return 0;  // auto: decided after measurement
+}
+
 int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
                  gw_boost_hit *hits, uint64_t max_hits, uint64_t *n_hits, uint64_t *n_pairs, double *vmax,
                  double *vmin, double *dense) {
@@ -998,7 +1005,8 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
                                 (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, max_hits,
                                 t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
                                 t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3,
-                                t->last_boost_kernel);
+                                t->last_boost_kernel, reinterpret_cast<unsigned int *>(t->d_tally + 4),
+                                (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t));
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1081,7 +1089,9 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
     GW_HIP(gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
                             (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, capacity,
                             tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
-                            t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel));
+                            t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel,
+                            reinterpret_cast<unsigned int *>(t->d_tally + 4), (uint32_t)t->compute_units * 2u,
+                            boost_stagger_ticks(t)));
     return GW_OK;
 }
 
@@ -1295,6 +1305,10 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_matrix_cores must be 0, 1 or 2");
         t->opt_boost_mfma = (int)v;
         return GW_OK;
+    case GW_OPT_BOOST_STAGGER_US:
+        if (v < -1 || v > 100000) return fail(GW_E_INVALID, "boost_stagger_us must be -1 (auto), 0 (off) or microseconds");
+        t->opt_boost_stagger = (int)v;
+        return GW_OK;
     case GW_OPT_DEFER_RECORDS:
         if (v < -1 || v > 1) return fail(GW_E_INVALID, "defer_records must be -1 (auto), 0 or 1");
         t->opt_defer = (int)v;
@@ -1337,6 +1351,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_PREFILTER_TRIPS: *v = (int64_t)t->prefilter_trips; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_DEFER_RECORDS: *v = sh.defer; return GW_OK;
+    case GW_OPT_BOOST_STAGGER_US: *v = boost_stagger_ticks(t) / 100u; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

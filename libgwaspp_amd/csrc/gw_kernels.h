@@ -145,7 +145,10 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         // diagnostic (prefilter + d_dense): write the bound's error bound instead of the bound
                         bool dense_err = false,
                         // char[96] or null: the kernel instantiation the launch went to, as rocprofv3 prints it
-                        char *kernel_name = nullptr);
+                        char *kernel_name = nullptr,
+                        // start-up stagger of the co-resident workgroups (BoostArgs::ticket in gw_boost_dev.h):
+                        // a device counter, the number of workgroups resident at once, ticks of the 100 MHz clock
+                        unsigned int *d_ticket = nullptr, uint32_t first_gen = 0, uint32_t stagger_ticks = 0);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

@@ -119,6 +119,6 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "run":
         run(sys.argv[2])
     elif len(sys.argv) >= 3 and sys.argv[1] == "merge":
-        merge(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r02")
+        merge(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r03")
     else:
         raise SystemExit(__doc__)
