@@ -379,6 +379,10 @@ typedef enum gw_option {
                                 gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
                                 512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
                                 scan workgroup that has to wait for one finishes its static share of the rows late */
+    GW_OPT_BOOST_LUT = 17,   /* pair screen of cohorts with at most 16 383 selected individuals and no missing call:
+                                1 = the persistent kernel whose single-precision bound looks its 27 logarithms up in an LDS
+                                table of k log2 k (k_boost_mfma_lut; an experiment of round 3: fewer vector instructions,
+                                but 123 vs 117 ms on config 5); 0 (default) the one-group-at-a-time kernel */
     GW_OPT_BOOST_STAGGER_US = 16, /* pair screen, one-group-at-a-time MFMA kernels: microseconds the workgroups in odd wave
                                 slots of the FIRST generation wait before they start, so that the two workgroups of a
                                 CU are out of step from then on (one's per-pair evaluation on the vector ALU runs under the

@@ -33,6 +33,7 @@ OPT_BOOST_PREFILTER_TRIPS = 12
 OPT_RESERVE_CUS = 14
 OPT_DEFER_RECORDS = 15
 OPT_BOOST_STAGGER_US = 16
+OPT_BOOST_LUT = 17
 
 
 class GwError(RuntimeError):

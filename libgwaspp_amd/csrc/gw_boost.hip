@@ -22,6 +22,7 @@
 // device code (measure, bound, operand expansion) in gw_boost_dev.h.
 #include "gw_boost_dev.h"
 
+#include <cmath>
 #include <cstdio>
 
 namespace gw {
@@ -136,6 +137,22 @@ __global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_in
             f.pa[3 * grp + g] = (float)m.pca[4 * grp + g];
         }
     }
+    double ki = 0.0, kj = 0.0;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const double n_grp = (double)(grp == 0 ? n_cases : n_ctrls);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const uint32_t k = grp == 0 ? m.cases[g] : m.ctrls[g];
+            if (!k) continue;
+            const double mg = (double)m.margins[g], kd = (double)k;
+            ki += kd * log2(mg / kd);
+            kj += kd * log2(mg * n_grp / (kd * n));
+        }
+    }
+    f.ki = (float)ki;
+    f.kj = (float)kj;
+    f.pad[0] = f.pad[1] = 0.0f;
     marf[r] = f;
 }
 
@@ -406,7 +423,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
                         float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name,
-                        unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks) {
+                        unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks, const float *d_klogk,
+                        uint32_t *d_park, int compute_units) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -416,6 +434,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.marf = d_marf; a.bound_threshold = bound_threshold; a.dense_err = dense_err ? 1 : 0;
     a.cct = d_cct;
     a.ticket = nullptr; a.first_gen = 0; a.stagger_ticks = 0;
+    a.lg_n = (float)(std::log2((double)(n_individs ? n_individs : 1u)) * 1.000001) + 1.0e-5f;
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
     // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)
@@ -423,6 +442,17 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
         if (kernel_name) std::snprintf(kernel_name, 96, fmt, x, y);
     };
     const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
+    a.klogk = d_klogk; a.park = d_park;
+    // small cohorts without a missing call: the persistent kernel with the bound's logarithms in an LDS table
+    if (d_cct && d_marf && small_case_group && fast && pre && !d_dense && d_klogk && d_park && n_individs <= 16383u) {
+        if (d_ticket && stagger_ticks) {  // one ticket counter per CU (4096 keys)
+            hipError_t e = hipMemsetAsync(d_ticket, 0, 4096 * sizeof(unsigned int), stream);
+            if (e != hipSuccess) return e;
+            a.ticket = d_ticket; a.stagger_ticks = stagger_ticks;
+        }
+        note("gw::k_boost_mfma_lut%s", "", "");
+        return launch_boost_mfma_lut4(a, compute_units, stream);
+    }
     if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
         if (d_ticket && stagger_ticks && !d_dense) {
             hipError_t e = hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);

@@ -107,6 +107,54 @@ __device__ __forceinline__ float boost_bound(const uint32_t (&ca)[9], const uint
     err = 5.9604645e-8f * (n * (58.0f + 87.0f * tao + 4.5f * fabsf(lt)) + 30.0f * fabsf(s) + 6.0f * fabsf(r));
     return r;
 }
+// The bound for tables WITHOUT a missing call (the four-corner kernels), with the logarithms split:
+//   z = k qb qa / (s n)  =>  sum_cells k log2 z = sum_cells k log2 k - sum_ab s log2 s + sum_cells k log2(qb qa / n),
+// and with no call missing the cells of a row / column of the pair's table add up to the SNPs' own genotype counts,
+// so the last sum is K_i + K_j, two numbers per SNP computed once in FP64 (SnpMarginF::ki, ::kj):
+//   measure = 2 ln 2 * [ sum_ab (x lg x + y lg y - s lg s) + K_i + K_j + n lg(tao) ],   lg = log2, s = x + y.
+// Per pair that is 27 v_log_f32 of integers, 27 multiply-adds and tao as 24 multiply-adds (tao = sum_a pa[a] * sum_b s_ab
+// rb[b] per group) -- no reciprocal, no product of margin factors per cell: about half the vector instructions of
+// boost_bound.  The price is conditioning: the three terms are each ~ n and cancel to O(1), so the error bound is
+// the larger u * n * (8.5 lg n + 69 + ...) -- 0.11 at n = 10 000, still a hundred times below the threshold.
+// Error bound, per operation (u = 2^-24; hardware assumptions as for boost_bound, checked at run time the same way):
+//   * float(k) exact; l = v_log_f32(k): |l - lg k| <= 2u lg k + 4u <= 2u Lg + 4u with Lg = lg n (k <= n);
+//     times k, summed over the 18 + 9 logarithms (sum of the k = 2n):            n u (4 Lg + 8)
+//   * per (a, b): e = x lx (rounded: u x Lg), e = fma(y, ly, e) (|e| <= s Lg: u s Lg), e = fma(-s, ls, e)
+//     (|e| <= s: u s):  u s (2 Lg + 1), summed:                                   n u (2 Lg + 1)
+//   * A += e, nine times, |A| <= n:                                               9 n u
+//   * K_i, K_j rounded to float (|K_i| <= n, |K_j| <= 1.07 n), (A + K_i) + K_j:   7.14 n u
+//   * tao: inputs rb, pa within u, 3 + 6 multiply-adds of non-negative terms: <= 11u relative (boost_bound: 13.1u),
+//     so as there n lt is within 23 u n + 3.02 u n |L|; R + n lt adds u (|final| + 2 n |L|)
+//   => before the factor 2 ln 2:  n u (6 Lg + 48.2) + 5.02 n u |L| + u |final|;  times 1.3863 and the factor's own
+//      two roundings (2.1 u |bound|):  u * [ n (8.32 Lg + 66.8 + 6.96 |L|) + 3.5 |bound| ];
+//   err below uses (8.5, 69, 7.2, 6).
+__device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                                   const SnpMarginF &f1, const SnpMarginF &f2, float n, float lg_n,
+                                                   float &err) {
+    float A = 0.0f, tao = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float in_c = 0.0f, in_t = 0.0f;  // sum_b s_ab rb[b], per group
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const uint32_t x = ca[3 * a + b], y = co[3 * a + b];
+            const float fx = (float)x, fy = (float)y, fs = (float)(x + y);
+            // k lg k with 0 lg 0 = 0: the logarithm of max(k, 1)
+            float e = fx * __log2f(fmaxf(fx, 1.0f));
+            e = __builtin_fmaf(fy, __log2f(fmaxf(fy, 1.0f)), e);
+            e = __builtin_fmaf(-fs, __log2f(fmaxf(fs, 1.0f)), e);
+            A += e;
+            in_c = __builtin_fmaf(fs, f2.rb[b], in_c);
+            in_t = __builtin_fmaf(fs, f2.rb[3 + b], in_t);
+        }
+        tao = __builtin_fmaf(f1.pa[a], in_c, tao);
+        tao = __builtin_fmaf(f1.pa[3 + a], in_t, tao);
+    }
+    const float lt = __log2f(tao);
+    const float r = 1.3862943611198906f * (((A + f1.ki) + f2.kj) + n * lt);  // 2 ln 2
+    err = 5.9604645e-8f * (n * (8.5f * lg_n + 69.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
+    return r;
+}
 // true: the pair is provably below the threshold (NaN / Inf anywhere -> false -> FP64 decides)
 __device__ __forceinline__ bool bound_rules_out(float bound, float err, float bound_threshold) {
     return bound + err < bound_threshold;
@@ -133,6 +181,9 @@ struct BoostArgs {
     const SnpMarginF *marf;     // PRE only
     const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
     float bound_threshold;      // PRE: the threshold rounded down to float; bound + err < this rules a pair out
+    float lg_n;                 // PRE: log2(n_individs), rounded up (boost_bound_split's error bound)
+    const float *klogk;         // k_boost_mfma_lut: k log2 k, k = 0 .. n_individs
+    uint32_t *park;             // k_boost_mfma_lut: 64 KB per resident workgroup for the parked case counts
     // Start-up stagger of the one-group-at-a-time MFMA kernels: a workgroup's life is a matrix-core phase (counting)
     // followed by a vector-ALU phase (the per-pair bound / measure), and the two workgroups a CU holds start
     // together and stay in step -- both count, then both evaluate, the matrix cores idle meanwhile.  The
@@ -195,5 +246,6 @@ hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t str
 hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq4.hip
 hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
 hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
+hipError_t launch_boost_mfma_lut4(const BoostArgs &a, int compute_units, hipStream_t stream);     // gw_boost_lut4.hip
 
 }  // namespace gw

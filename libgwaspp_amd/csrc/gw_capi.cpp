@@ -79,6 +79,8 @@ struct gw_table {
     uint32_t wc = 0, wt = 0;
     gw::SnpMargin *d_mar = nullptr;
     gw::SnpMarginF *d_marf = nullptr;
+    float *d_klogk = nullptr;    // k log2 k, k = 0 .. sel_individs (k_boost_mfma_lut; cohorts of at most 16 383)
+    uint32_t *d_park = nullptr;  // ... and 64 KB per resident workgroup for its parked case counts
     gw::u32x4 *d_cct = nullptr;  // block-tiled copy of d_cc for the MFMA pair kernel (tables without missing calls)
     double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
@@ -96,7 +98,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0;
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -398,6 +400,8 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_raw) (void)hipFree(t->d_raw);
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
+    if (t->d_klogk) (void)hipFree(t->d_klogk);
+    if (t->d_park) (void)hipFree(t->d_park);
     if (t->d_tally) (void)hipFree(t->d_tally);
     if (t->d_hits_buf) (void)hipFree(t->d_hits_buf);
     if (t->d_dense_buf) (void)hipFree(t->d_dense_buf);
@@ -865,7 +869,8 @@ int ensure_selected(gw_table *t) {
         if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
         if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
     }
-    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 6 * sizeof(unsigned long long)));  // [4]: launch ticket counter
+    // [0..3] the kernels' tally, [4..] 4096 uint32 ticket counters (start-up stagger of the pair kernels)
+    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long) + 4096 * sizeof(unsigned int)));
     if (m) {
         if (!t->d_cc) GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
         if (!t->d_mar) GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
@@ -915,10 +920,15 @@ int ensure_selected(gw_table *t) {
     if (!t->d_frac || individs != t->sel_individs) {  // the k/n and (k/n) log(k/n) tables depend on n only
         if (t->d_frac) { GW_HIP(hipFree(t->d_frac)); t->d_frac = nullptr; }
         if (t->d_xlogx) { GW_HIP(hipFree(t->d_xlogx)); t->d_xlogx = nullptr; }
+        if (t->d_klogk) { GW_HIP(hipFree(t->d_klogk)); t->d_klogk = nullptr; }
         GW_HIP(hipMalloc((void **)&t->d_frac, ((size_t)individs + 1u) * sizeof(double)));
         GW_HIP(hipMalloc((void **)&t->d_xlogx, ((size_t)individs + 1u) * sizeof(double)));
+        if (individs <= 16383u)  // k_boost_mfma_lut: k log2 k, and the parking space of its resident workgroups
+            GW_HIP(hipMalloc((void **)&t->d_klogk, ((size_t)individs + 1u) * sizeof(float)));
     }
+    if (t->d_klogk && !t->d_park) GW_HIP(hipMalloc((void **)&t->d_park, gw::boost_lut_park_bytes(t->compute_units)));
     t->sel_individs = individs;
+    if (t->d_klogk) GW_HIP(gw::launch_boost_klogk(t->sel_individs + 1u, t->d_klogk, t->stream));
     GW_HIP(gw::launch_boost_tables(t->sel_individs + 1u, t->sel_individs, t->d_frac, t->d_xlogx, t->stream));
     GW_HIP(hipStreamSynchronize(t->stream));
     t->any_missing = false;
@@ -1006,7 +1016,8 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
                                 t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
                                 t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3,
                                 t->last_boost_kernel, reinterpret_cast<unsigned int *>(t->d_tally + 4),
-                                (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t));
+                                (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t),
+                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units);
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1091,7 +1102,7 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
                             tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
                             t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel,
                             reinterpret_cast<unsigned int *>(t->d_tally + 4), (uint32_t)t->compute_units * 2u,
-                            boost_stagger_ticks(t)));
+                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units));
     return GW_OK;
 }
 
@@ -1305,6 +1316,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > 2) return fail(GW_E_INVALID, "boost_matrix_cores must be 0, 1 or 2");
         t->opt_boost_mfma = (int)v;
         return GW_OK;
+    case GW_OPT_BOOST_LUT:
+        t->opt_boost_lut = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_BOOST_STAGGER_US:
         if (v < -1 || v > 100000) return fail(GW_E_INVALID, "boost_stagger_us must be -1 (auto), 0 (off) or microseconds");
         t->opt_boost_stagger = (int)v;
@@ -1352,6 +1366,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_DEFER_RECORDS: *v = sh.defer; return GW_OK;
     case GW_OPT_BOOST_STAGGER_US: *v = boost_stagger_ticks(t) / 100u; return GW_OK;
+    case GW_OPT_BOOST_LUT: *v = t->opt_boost_lut; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

@@ -111,6 +111,10 @@ struct SnpMarginF {
     float qa[6];  // margins[g] / group[g]             = 1 / P(status | g)
     float rb[6];  // P(g | status) / margins[g]
     float pa[6];  // P(status | g)
+    // the SNP's share of sum_cells k log2(qb qa / n) when the table has no missing call (boost_bound_split):
+    //   ki = sum_g group[g] log2(qa[g])          the SNP as the pair's first marker
+    //   kj = sum_g group[g] log2(qb[g] / n)      ... as its second
+    float ki, kj, pad[2];
 };
 struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
     uint32_t snp_a, snp_b;
@@ -148,7 +152,12 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         char *kernel_name = nullptr,
                         // start-up stagger of the co-resident workgroups (BoostArgs::ticket in gw_boost_dev.h):
                         // a device counter, the number of workgroups resident at once, ticks of the 100 MHz clock
-                        unsigned int *d_ticket = nullptr, uint32_t first_gen = 0, uint32_t stagger_ticks = 0);
+                        unsigned int *d_ticket = nullptr, uint32_t first_gen = 0, uint32_t stagger_ticks = 0,
+                        // k_boost_mfma_lut (cohorts of at most 16 383 without a missing call): k log2 k for
+                        // k = 0 .. n_individs, boost_lut_park_bytes() of scratch, the device's CU count; null = not used
+                        const float *d_klogk = nullptr, uint32_t *d_park = nullptr, int compute_units = 0);
+hipError_t launch_boost_klogk(uint32_t n_entries, float *d_klogk, hipStream_t stream);
+size_t boost_lut_park_bytes(int compute_units);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);
