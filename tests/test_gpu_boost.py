@@ -288,3 +288,32 @@ def test_new_masks_on_the_same_table_reuse_the_selection_buffers(oracle):
             for r in (0, m - 1):
                 ca, co = oracle.stream_cc_dist(ts[r], gs, cs, ct, nc, nt)
                 assert tuple(int(v) for v in rec[r]["cases"]) == tuple(ca) and tuple(int(v) for v in rec[r]["controls"]) == tuple(co)
+
+
+@pytest.mark.parametrize("n,m", [(600, 48), (3000, 500), (9000, 1400)])
+def test_lut_kernel_gives_the_same_hit_list(n, m):
+    """GW_OPT_BOOST_LUT = 1 (the persistent kernel with the bound's logarithms in an LDS table, case counts parked in
+    global memory; cohorts <= 16 383 without a missing call) against the default kernel: same hits, same FP64 measures,
+    same pair tally, for block and whole-triangle calls, host and device-list forms; the pre-filter's error model holds."""
+    with gw.GwTable(n, m) as t:
+        t.simulate(11, 3, 0)
+        t.simulate_phenotype(11)
+        calls = [(0, m, 0, m), (0, m // 3, 0, m), (m // 3, m - m // 3, m // 3, m - m // 3), (5, 130, 70, m - 70)]
+        for thr in (30.0, 6.0, -1.0e9):
+            for (a, na, b, nb) in calls:
+                t.set_option(gw.capi.OPT_BOOST_LUT, 0)
+                want, wh, wp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
+                k0 = t.last_boost_kernel()
+                t.set_option(gw.capi.OPT_BOOST_LUT, 1)
+                got, gh, gp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
+                assert k0.startswith("gw::k_boost_mfma_seq<true, 2, 2") and t.last_boost_kernel() == "gw::k_boost_mfma_lut"
+                assert (gh, gp) == (wh, wp)
+                assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
+    # a table with missing calls, or a cohort above 16 383, never takes it
+    with gw.GwTable(2000, 100) as t:
+        t.simulate(11, 3, 655)
+        t.simulate_phenotype(11)
+        t.set_option(gw.capi.OPT_BOOST_LUT, 1)
+        t.boost_screen(0, 100, 0, 100, extremes=False)
+        assert t.last_boost_kernel().startswith("gw::k_boost_mfma_seq<true, 3, 1")

@@ -90,3 +90,24 @@ def test_all_pairs_kernels_count_what_the_text_holds(oracle, name):
     for r in range(m):   # the device margins are the text's single-SNP counts
         assert tuple(int(v) for v in rec[r]["cases"]) == mar[r].cases.tuple()
         assert tuple(int(v) for v in rec[r]["controls"]) == mar[r].controls.tuple()
+
+
+@pytest.mark.parametrize("name", golden_sets("plain"))
+def test_gpu_masked_scan_with_missing_calls_equals_text_counts(oracle, name):
+    """The north-star kernel on the reference generator's rows WITH missing calls (25 %), groups laid over them
+    (tests/test_pair_text_pin.py split_groups): per-group counts straight from the .tped text, a sample in neither group."""
+    from test_pair_text_pin import split_groups
+    n = int(name.split("_n")[1])
+    lines = read_tped(name)
+    cases, ctrls, _ = split_groups(name, n)
+    ts = oracle.pack_rows([oracle.tped_genotype_text(ln) for ln in lines], n, "stream")
+    _, sm_c, nc = oracle.ccs_masks(cases, n)
+    _, sm_t, nt = oracle.ccs_masks(ctrls, n)
+    with gw.GwTable(n, len(lines)) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(sm_c, sm_t, nc, nt)
+        counts, _ = t.scan_case_control()
+    for r, ln in enumerate(lines):
+        cls = row_classes(ln)
+        want = [int(v) for g in (cases, ctrls) for v in np.bincount(cls[g], minlength=4)[:4]]
+        assert [int(v) for v in counts[r]] == want

@@ -64,3 +64,37 @@ def test_oracle_pair_tables_equal_text_counts(oracle, name):
         bc, bt = oracle.block_cc_contingency(tb[i], tb[j], gb, bm_c, bm_t)
         assert np.array_equal(bc[NINE], joint_counts(cls[i], cls[j], cases)[NINE])
         assert np.array_equal(bt[NINE], joint_counts(cls[i], cls[j], ctrls)[NINE])
+
+
+def split_groups(name, n):
+    """A seeded three-way split (case / control / neither) laid over a 'plain' golden set -- the reference generator's
+    --case-control mode writes no missing call, its plain mode no groups; the masked scan WITH missing calls is pinned
+    by putting groups on the plain sets' rows (25 % missing calls) and counting classes per group from the text."""
+    rng = np.random.default_rng(sum(map(ord, name)))   # a seed that does not depend on the interpreter's hash salt
+    status = rng.integers(0, 3, size=n)
+    return np.flatnonzero(status == 1), np.flatnonzero(status == 0), np.flatnonzero(status == 2)
+
+
+@pytest.mark.parametrize("name", golden_sets("plain"))
+def test_oracle_masked_scan_with_missing_calls_equals_text_counts(oracle, name):
+    """getCaseControlGenotypeDistribution (table5.cpp:609-657, table3.cpp:596-640) on rows WITH missing calls: per group
+    aa / ab / bb from the .tped text, xx = group - aa - ab - bb (table5.cpp:649,653); and the three groups' counts add
+    up, class for class, to the generator's own expected file for the row."""
+    from golden_util import expected_in_table_space, read_dist
+    n = _n_of(name)
+    lines, exp = read_tped(name), read_dist(name, "dist")
+    cases, ctrls, rest = split_groups(name, n)
+    gs, gb = oracle.geometry_stream(n), oracle.geometry_block(n)
+    texts = [oracle.tped_genotype_text(ln) for ln in lines]
+    ts, tb = oracle.pack_rows(texts, n, "stream"), oracle.pack_rows(texts, n, "block")
+    bm_c, sm_c, nc = oracle.ccs_masks(cases, n)
+    bm_t, sm_t, nt = oracle.ccs_masks(ctrls, n)
+    for r, ln in enumerate(lines):
+        cls = row_classes(ln)
+        per = [np.bincount(cls[g], minlength=4) for g in (cases, ctrls, rest)]
+        total = per[0] + per[1] + per[2]
+        assert (int(total[0]), int(total[1]), int(total[2]), int(total[3])) == expected_in_table_space(exp[r], ln)
+        ca, co = oracle.stream_cc_dist(ts[r], gs, sm_c, sm_t, nc, nt)
+        assert tuple(ca) == tuple(int(v) for v in per[0]) and tuple(co) == tuple(int(v) for v in per[1])
+        ba, bo = oracle.block_cc_dist(tb[r], gb, bm_c, bm_t)       # the block table leaves xx at 0 (quirk Q3)
+        assert tuple(ba)[:3] == tuple(int(v) for v in per[0][:3]) and tuple(bo)[:3] == tuple(int(v) for v in per[1][:3])
