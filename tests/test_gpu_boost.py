@@ -298,7 +298,8 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
     with gw.GwTable(n, m) as t:
         t.simulate(11, 3, 0)
         t.simulate_phenotype(11)
-        calls = [(0, m, 0, m), (0, m // 3, 0, m), (m // 3, m - m // 3, m // 3, m - m // 3), (5, 130, 70, m - 70)]
+        calls = [(0, m, 0, m), (0, m // 3, 0, m), (m // 3, m - m // 3, m // 3, m - m // 3),
+                 (5, min(130, m - 5), min(70, m // 2), m - min(70, m // 2))]
         for thr in (30.0, 6.0, -1.0e9):
             for (a, na, b, nb) in calls:
                 t.set_option(gw.capi.OPT_BOOST_LUT, 0)
