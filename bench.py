@@ -100,8 +100,15 @@ def parse_args():
 
 
 def kernel_source_sha16():
-    with open(KERNEL_SOURCE, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    """sha256[:16] over every kernel source of the library (libgwaspp_amd/csrc/*.hip, *.inc, *.h, sorted by name): the stamp
+    a committed PMC figure carries (tools/collect_pmc.py computes the same)."""
+    import glob
+    h = hashlib.sha256()
+    d = os.path.dirname(KERNEL_SOURCE)
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h"))):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def git_head():
@@ -207,7 +214,7 @@ def cpu_baseline_c1(seconds=4.0):
     n, m, text = WORKLOADS["c1"]
     g = oracle.geometry_stream(n)
     with gw.GwTable(n, m) as t:
-        t.simulate(SEED, 0, 0)
+        t.simulate(SEED, 0, 0, exact=True)
         t.simulate_phenotype(SEED)
         rows = t.download_rows(0, m)
         cs, ct, nc, nt = t.get_case_control()
@@ -246,32 +253,6 @@ def cpu_baseline_c1(seconds=4.0):
                                "achieved_GBps": m * (n / 4.0) / (gpu_ms * 1e-3) / 1e9,
                                "frac": m * (n / 4.0) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": gpu_kernel,
                                "note": "0.125 GB table, resident in the 256 MB Infinity Cache"}}
-
-
-def side_workload(name, steps, warmup):
-    """The same scan on another BASELINE.json shape (its own table), reported inside the JSON line
-    for information; not part of `value`."""
-    import torch
-    import libgwaspp_amd as gw
-    n, m, text = WORKLOADS[name]
-    with gw.GwTable(n, m) as t:
-        t.simulate(SEED, 0, 0)
-        t.simulate_phenotype(SEED)
-        buf = torch.empty(m * RECORD_BYTES, dtype=torch.uint8, device="cuda")
-        base = buf.data_ptr()
-        for _ in range(warmup):
-            t.scan_case_control_device(0, m, base, base + m * 32, None)
-        t.synchronize()
-        t.timer_start(None)
-        for _ in range(steps):
-            t.scan_case_control_device(0, m, base, base + m * 32, None)
-        ms = t.timer_stop(None) / steps
-        gbps = m * (n / 4.0) / (ms * 1e-3) / 1e9
-        kernel = t.last_scan_kernel()
-        traffic, traffic_note = pmc_traffic(name, kernel)
-        return {"workload": text, "ms_per_step": ms, "value": m / (ms * 1e-3), "unit": "SNPs/s",
-                "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "kernel": kernel,
-                "algorithmic_bytes_per_launch": m * (n / 4.0), "traffic": traffic, "traffic_source": traffic_note}
 
 
 def dropin_walk(name):
@@ -315,7 +296,7 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
     if args.snps and args.workload == "c5":
         n_snps = args.snps
     table = gw.GwTable(n_samples, n_snps, device=local_rank)
-    table.simulate(SEED, 0, 0)               # every rank generates the same table (counter-based RNG); a job
+    table.simulate(SEED, 0, 0, exact=True)   # every rank generates the same table (counter-based RNG); a job
     table.simulate_phenotype(SEED)           # with ingested rows replicates them with gw_table_replicate instead
     blocks = gw.shard_pair_blocks(n_snps, rank, world, block=2048)
     cap = 1 << 18
@@ -381,6 +362,8 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
         want = np.sort(want, order=["snp_a", "snp_b"])
         rehearsal_ok = bool(wh == n_hits and wp == n_pairs and np.array_equal(got, want))
     out = None
+    c5_traffic = (pmc_traffic("c5", kernel_name) if world == 1 and not args.snps and len(blocks) == 1
+                  else (None, "PMC figure is per whole-triangle launch on one GPU"))
     if rank == 0:
         per_step = elapsed / steps
         # no missing calls in the synthetic table: 4 counted corners per pair and group, each a dot product
@@ -403,7 +386,8 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
             "roofline": {"bound": "mfma", "achieved": 2.0 * macs / per_step / 1e12, "peak": MFMA_I8_PEAK_TOPS,
                          "unit": "TOP/s (int8, 2 ops per multiply-add; wall time of the whole screen incl. the "
                                  "per-pair bound / measure epilogue and host round trips)",
-                         "frac": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
+                         "frac": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS,
+                         "traffic": c5_traffic[0], "traffic_source": c5_traffic[1],
                          "kernel": kernel_name, "kernel_ms": kernel_ms_total / steps,
                          "launches_per_step": len(blocks),
                          "note": "algorithmic MACs only (sample padding to 1024 per group not counted); kernel_ms = HIP "
@@ -531,7 +515,7 @@ def main():
     reserve_cus = args.reserve_cus if args.reserve_cus >= 0 else (8 if world > 1 else 0)
     table.set_option(capi.OPT_RESERVE_CUS, reserve_cus)
     t_setup = time.perf_counter()
-    table.simulate(SEED, begin, 0)           # rows of ONE table: row r of this rank = global SNP begin + r
+    table.simulate(SEED, begin, 0, exact=True)  # rows of ONE table: row r of this rank = global SNP begin + r
     table.simulate_phenotype(SEED)           # identical masks on every rank (same seed)
     t_setup = time.perf_counter() - t_setup
 
@@ -703,7 +687,8 @@ def main():
                 "workload": wl_text, "n_samples": n_samples, "n_snps_per_gpu": n_local,
                 "n_snps_total": n_total, "table_GB_per_gpu": geo.device_table_bytes / 1e9,
                 "algorithmic_bytes_per_snp": n_samples / 4.0,
-                "input": f"restated data/simulate_data.cpp (affy6 MAF spectrum, HWE, coin-flip phenotype), "
+                "input": f"restated data/simulate_data.cpp (affy6 MAF spectrum, exactly floor(p * 2N) minor alleles per SNP "
+                         f"in a random arrangement as its shuffle gives, coin-flip phenotype), "
                          f"counter-based RNG seed {SEED:#x}, generated in HBM in {t_setup:.2f} s",
                 "sharding": (f"contiguous SNP ranges of one {n_total}-SNP table, one rank per GPU (rank 0: "
                              f"[{begin}, {begin + n_local}))" if strong else
@@ -731,7 +716,7 @@ def main():
     if rehearse and rank == 0:
         import numpy as np
         with gw.GwTable(n_samples, n_total, device=0) as whole:
-            whole.simulate(SEED, 0 if strong else 0, 0)
+            whole.simulate(SEED, 0 if strong else 0, 0, exact=True)
             whole.simulate_phenotype(SEED)
             counts, stats = whole.scan_case_control()
         ok = True
@@ -767,16 +752,33 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"]["c1"] = cpu_baseline_c1()
         if not args.no_extra:
-            extra = {"c2": side_workload("c2", args.steps, args.warmup),
-                     "n10k": side_workload("n10k", args.steps, args.warmup),
-                     "dropin_walk_c2": dropin_walk("c2")}
-            c5 = bench_pairs(args, 0, 1, local_rank, None, steps=3, warmup=1, with_cpu_baseline=not args.no_cpu_baseline)
-            extra["c5"] = {"workload": c5["config"]["workload"], "ms_per_step": c5["ms_per_step"],
-                           "value": c5["value"], "unit": c5["unit"], "pairs": c5["config"]["pairs"],
-                           "hits_over_30": c5["config"]["hits_over_30"],
-                           "mfma_int8_TOPs": c5["roofline"]["achieved"], "frac": c5["roofline"]["frac"],
-                           "bound": "mfma", "kernel": c5["roofline"]["kernel"], "kernel_ms": c5["roofline"]["kernel_ms"],
-                           "steps": c5["steps"], "cpu_baseline": c5["cpu_baseline"]}
+            # each side workload in a process of its own, after this one has freed its 125 GB: the same command line a
+            # user would run (`bench.py --workload c2`), and a table allocated from an untouched heap -- inside this
+            # process, right after the big table was freed, the 2.5 GB table of n10k measured 10 % slower
+            def side(name, steps, warmup, cpu):
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", str(warmup),
+                       "--no-extra"] + ([] if cpu else ["--no-cpu-baseline"])
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode != 0 or not line:
+                    return {"workload": WORKLOADS[name][2], "error": f"exit {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                d = json.loads(line[-1])
+                rf = d["roofline"]
+                e = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                     "steps": d["steps"], "frac": rf["frac"], "bound": rf["bound"], "kernel": rf["kernel"],
+                     "kernel_ms": rf.get("kernel_ms"), "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                     "command": "python bench.py " + " ".join(cmd[2:])}
+                if rf["bound"] == "hbm":
+                    e["achieved_GBps"] = rf["achieved"]
+                    e["algorithmic_bytes_per_launch"] = rf["algorithmic_bytes_per_launch"]
+                else:
+                    e.update({"pairs": d["config"]["pairs"], "hits_over_30": d["config"]["hits_over_30"],
+                              "mfma_int8_TOPs": rf["achieved"], "cpu_baseline": d.get("cpu_baseline")})
+                return e
+            extra = {"c2": side("c2", args.steps, args.warmup, False),
+                     "n10k": side("n10k", args.steps, args.warmup, False),
+                     "dropin_walk_c2": dropin_walk("c2"),
+                     "c5": side("c5", 3, 1, not args.no_cpu_baseline)}
             out["extra_workloads"] = extra
     if out is not None:
         print(json.dumps(out))

@@ -138,6 +138,11 @@ int gw_table_get_headers(gw_table *t, uint64_t snp_begin, uint64_t n_rows, uint1
  * missing-call probability * 65536 (0 = none, like the reference simulator).
  * gw_table_simulate_phenotype also installs the case/control masks. */
 int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16);
+/* The same, with the reference simulator's exact allele count: a SNP gets exactly floor(p * 2 n_samples) minor alleles
+ * in a uniformly random arrangement (simulate_data.cpp:191-205 fills s 'B's and shuffles the 2N alleles), where
+ * gw_table_simulate draws every allele independently with probability p (binomial count).  Same p per SNP, same missing
+ * calls, same phenotype.  GW_E_RANGE for cohorts beyond about 6 million samples. */
+int gw_table_simulate_exact(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16);
 int gw_table_simulate_phenotype(gw_table *t, uint64_t seed);
 
 /* ---- phenotype masks -----------------------------------------------------

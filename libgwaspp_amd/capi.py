@@ -87,7 +87,7 @@ _lib = None
 EXPORTS = [
     "gw_last_error", "gw_version", "gw_device_count", "gw_device_info_get", "gw_table_create",
     "gw_table_destroy", "gw_table_geometry", "gw_table_add_genotype_row", "gw_table_add_genotype_rows", "gw_table_flush",
-    "gw_table_upload_rows", "gw_table_download_rows", "gw_table_get_headers", "gw_table_simulate",
+    "gw_table_upload_rows", "gw_table_download_rows", "gw_table_get_headers", "gw_table_simulate", "gw_table_simulate_exact",
     "gw_table_simulate_phenotype", "gw_table_set_case_control", "gw_table_get_case_control",
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
@@ -125,6 +125,7 @@ def library() -> C.CDLL:
     L.gw_table_download_rows.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_int]
     L.gw_table_get_headers.argtypes = [vp, C.c_uint64, C.c_uint64, u16p]
     L.gw_table_simulate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.gw_table_simulate_exact.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32]
     L.gw_table_simulate_phenotype.argtypes = [vp, C.c_uint64]
     L.gw_table_set_case_control.argtypes = [vp, u16p, u16p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.gw_table_get_case_control.argtypes = [vp, u16p, u16p, C.c_uint32, u32p, u32p]
@@ -390,8 +391,10 @@ class GwTable:
         _check(self._L.gw_table_get_headers(self._h, snp_begin, n_rows, _p16(h)))
         return h
 
-    def simulate(self, seed: int, snp_global_begin: int = 0, missing_q16: int = 0):
-        _check(self._L.gw_table_simulate(self._h, seed, snp_global_begin, missing_q16))
+    def simulate(self, seed: int, snp_global_begin: int = 0, missing_q16: int = 0, exact: bool = False):
+        """exact=True: the reference simulator's exact minor-allele count per SNP (gw_table_simulate_exact)"""
+        f = self._L.gw_table_simulate_exact if exact else self._L.gw_table_simulate
+        _check(f(self._h, seed, snp_global_begin, missing_q16))
 
     def simulate_phenotype(self, seed: int):
         _check(self._L.gw_table_simulate_phenotype(self._h, seed))

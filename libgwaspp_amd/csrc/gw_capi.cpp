@@ -621,6 +621,25 @@ int gw_table_simulate(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uin
     return GW_OK;
 }
 
+int gw_table_simulate_exact(gw_table *t, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16) {
+    if (!t) return fail(GW_E_INVALID, "NULL table");
+    if (missing_q16 > 65535u) return fail(GW_E_INVALID, "missing_q16 must be < 65536");
+    int rc = use_device(t, true);
+    if (rc) return rc;
+    t->pending_rows = 0;
+    t->selected_valid = false;
+    GW_HIP(hipMemsetAsync(t->d_misc + 8, 0, sizeof(uint32_t), t->stream));
+    GW_HIP(gw::launch_simulate_exact(t->tv, seed, snp_global_begin, missing_q16, t->compute_units * 4, t->d_misc + 8, t->stream));
+    uint32_t overflow = 0;
+    GW_HIP(hipMemcpyAsync(&overflow, t->d_misc + 8, sizeof overflow, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    if (overflow)
+        return fail(GW_E_RANGE, "gw_table_simulate_exact: %u rows of %u samples exceeded the selection list (cohort too large)",
+                    overflow, t->geo.n_samples);
+    std::fill(t->headers.begin(), t->headers.end(), (uint16_t)0x7015);
+    return GW_OK;
+}
+
 int gw_table_simulate_phenotype(gw_table *t, uint64_t seed) {
     if (!t) return fail(GW_E_INVALID, "NULL table");
     int rc = use_device(t);

@@ -90,6 +90,10 @@ hipError_t launch_mask_in(const uint16_t *d_src, uint32_t n_blocks, u32x4 *d_mas
 // synthetic input (restates data/simulate_data.cpp, see gw_kernels.hip)
 hipError_t launch_simulate(const TableView &tv, uint64_t seed, uint64_t snp_global_begin,
                            uint32_t missing_q16, int grid_blocks, hipStream_t stream);
+// ... with exactly floor(p * 2N) minor alleles per SNP, as the reference simulator's shuffle gives (simulate_data.cpp:191-205);
+// *d_overflow is bumped for a row whose selection list did not fit (cohorts beyond ~6 M samples)
+hipError_t launch_simulate_exact(const TableView &tv, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16,
+                                 int grid_blocks, uint32_t *d_overflow, hipStream_t stream);
 hipError_t launch_simulate_phenotype(uint64_t seed, u32x4 *d_case, u32x4 *d_ctrl, uint32_t units,
                                      uint32_t n_samples, uint32_t *d_counts2, hipStream_t stream);
 

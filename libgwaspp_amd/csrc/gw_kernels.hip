@@ -1445,6 +1445,151 @@ hipError_t launch_simulate(const TableView &tv, uint64_t seed, uint64_t snp_glob
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// The same generator with the reference simulator's EXACT minor-allele count (data/simulate_data.cpp:191-205: exactly
+// s = floor(p * 2N) 'B' alleles among the 2N alleles of a SNP, shuffled; consecutive allele pairs are the genotypes).
+// A uniformly random arrangement of s marked alleles among 2N = the s smallest of 2N independent random keys: allele
+// `pos` of the row gets the 32-bit key below (one splitmix64 per sample gives the keys of its two alleles), and the
+// minor alleles are the s positions with the smallest (key, pos).  One workgroup per row finds the s-th smallest pair
+// by a 4096-bin histogram of the keys' top 12 bits, an exact rank inside the one bin the order statistic falls in
+// (about 2N / 4096 keys, held in LDS), and then writes the planes: three passes over the row's keys, nothing stored.
+// oracle/gw_oracle.c gwo_sim_row_stream_exact is the same rule with a sort.
+// ---------------------------------------------------------------------------
+#define SIM_ALLELE_MUL 0x9FB21C651E98DF25ull
+constexpr uint32_t SIM_BINS = 4096, SIM_LIST_CAP = 4096;
+
+__device__ __forceinline__ uint64_t allele_keys(uint64_t rowkey, uint32_t sample) {  // alleles 2c (high half), 2c + 1 (low half)
+    return splitmix64(rowkey + SIM_ALLELE_MUL * (uint64_t)(sample + 1u));
+}
+
+__global__ void __launch_bounds__(512) k_simulate_exact(u32x4 *table, uint64_t row_stride_u, uint32_t plane_stride_u,
+                                                        uint32_t n_samples, uint64_t n_rows, uint64_t seed, uint64_t snp0,
+                                                        uint32_t missing_q16, uint32_t *overflow) {
+    __shared__ uint32_t s_hist[SIM_BINS];
+    __shared__ unsigned long long s_list[SIM_LIST_CAP];
+    __shared__ uint32_t s_scan[512];
+    __shared__ uint32_t s_bin, s_below, s_count;
+    __shared__ unsigned long long s_thr;
+    const uint32_t t = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const uint64_t key = splitmix64(seed + SIM_SNP_MUL * (snp0 + r + 1));
+        uint64_t pick = splitmix64(key ^ 1u) % K_AFFY6_TOTAL;
+        uint32_t bin = 0;
+        while (pick >= k_affy6[bin]) { pick -= k_affy6[bin]; ++bin; }
+        const uint32_t p_e5 = bin * 1000u + (uint32_t)(splitmix64(key ^ 2u) % 1000u);
+        const uint32_t s = (uint32_t)(((uint64_t)p_e5 * 2ull * n_samples) / 100000ull);  // floor(p * 2N), simulate_data.cpp:193
+
+        // ---- 1. histogram of the keys' top 12 bits
+        __syncthreads();
+        for (uint32_t k = t; k < SIM_BINS; k += 512u) s_hist[k] = 0;
+        if (t == 0) { s_count = 0; s_bin = 0xFFFFFFFFu; s_below = 0; s_thr = 0; }
+        __syncthreads();
+        for (uint32_t c = t; c < n_samples; c += 512u) {
+            const uint64_t h = allele_keys(key, c);
+            atomicAdd(&s_hist[(uint32_t)(h >> 52)], 1u);
+            atomicAdd(&s_hist[((uint32_t)h) >> 20], 1u);
+        }
+        __syncthreads();
+        // ---- 2. the bin the s-th smallest key falls in (8 bins per thread, scan over the 512 partial sums)
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) mine += s_hist[8u * t + k];
+        s_scan[t] = mine;
+        __syncthreads();
+        for (uint32_t d = 1; d < 512u; d <<= 1) {
+            const uint32_t v = t >= d ? s_scan[t - d] : 0u;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const uint32_t incl = s_scan[t], excl = incl - mine;
+        if (s >= 1u && excl < s && s <= incl) {
+            uint32_t below = excl;
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t hcount = s_hist[8u * t + k];
+                if (s <= below + hcount) { s_bin = 8u * t + k; s_below = below; break; }
+                below += hcount;
+            }
+        }
+        __syncthreads();
+        const uint32_t the_bin = s_bin, rank = s - s_below;  // the rank-th smallest (1-based) of that bin is the last minor allele
+        // ---- 3. that bin's (key, pos) pairs, and the one of them with rank - 1 smaller ones
+        if (the_bin != 0xFFFFFFFFu) {
+            for (uint32_t c = t; c < n_samples; c += 512u) {
+                const uint64_t h = allele_keys(key, c);
+                const uint32_t k0 = (uint32_t)(h >> 32), k1 = (uint32_t)h;
+                if ((k0 >> 20) == the_bin) {
+                    const uint32_t slot = atomicAdd(&s_count, 1u);
+                    if (slot < SIM_LIST_CAP) s_list[slot] = ((unsigned long long)k0 << 32) | (2u * c);
+                }
+                if ((k1 >> 20) == the_bin) {
+                    const uint32_t slot = atomicAdd(&s_count, 1u);
+                    if (slot < SIM_LIST_CAP) s_list[slot] = ((unsigned long long)k1 << 32) | (2u * c + 1u);
+                }
+            }
+            __syncthreads();
+            const uint32_t cnt = s_count;
+            if (cnt > SIM_LIST_CAP) {
+                if (t == 0) atomicAdd(overflow, 1u);  // cohorts beyond ~6 M samples: reported by the host, nothing is wrong silently
+            } else {
+                for (uint32_t e = t; e < cnt; e += 512u) {
+                    const unsigned long long v = s_list[e];
+                    uint32_t smaller = 0;
+                    for (uint32_t q = 0; q < cnt; ++q) smaller += s_list[q] < v ? 1u : 0u;
+                    if (smaller == rank - 1u) s_thr = v;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned long long thr = s_thr;
+        const bool any = the_bin != 0xFFFFFFFFu;
+        // ---- 4. the planes: allele `pos` is the minor allele iff (key, pos) <= thr
+        u32x4 *d0 = table + r * row_stride_u;
+        u32x4 *d1 = d0 + plane_stride_u;
+        for (uint32_t u = t; u < plane_stride_u; u += 512u) {
+            uint64_t a[2], b[2];
+#pragma unroll
+            for (uint32_t hh = 0; hh < 2; ++hh) {
+                const uint32_t w = 2u * u + hh;
+                const uint64_t valid = valid_bits(w, n_samples);
+                a[hh] = 0; b[hh] = 0;
+                if (valid) {
+                    uint64_t m1 = 0, m2 = 0;
+                    for (uint32_t bit = 0; bit < 64u; ++bit) {
+                        const uint32_t c = w * 64u + bit;
+                        if (c >= n_samples) break;
+                        const uint64_t h = allele_keys(key, c);
+                        const unsigned long long e0 = ((h >> 32) << 32) | (2u * c), e1 = ((h & 0xFFFFFFFFull) << 32) | (2u * c + 1u);
+                        m1 |= (uint64_t)(any && e0 <= thr) << bit;
+                        m2 |= (uint64_t)(any && e1 <= thr) << bit;
+                    }
+                    uint64_t x = ~(m1 ^ m2), y = m1 | m2;
+                    if (missing_q16) {
+                        const uint64_t wkey = key + SIM_WORD_MUL * (uint64_t)(w + 1);
+                        const uint64_t miss = bernoulli64(wkey, 32, missing_q16);
+                        x &= ~miss;
+                        y &= ~miss;
+                    }
+                    a[hh] = x & valid;
+                    b[hh] = y & valid;
+                }
+            }
+            u32x4 lo = {(uint32_t)a[0], (uint32_t)(a[0] >> 32), (uint32_t)a[1], (uint32_t)(a[1] >> 32)};
+            u32x4 hi = {(uint32_t)b[0], (uint32_t)(b[0] >> 32), (uint32_t)b[1], (uint32_t)(b[1] >> 32)};
+            d0[u] = lo;
+            d1[u] = hi;
+        }
+    }
+}
+
+hipError_t launch_simulate_exact(const TableView &tv, uint64_t seed, uint64_t snp_global_begin, uint32_t missing_q16,
+                                 int grid_blocks, uint32_t *d_overflow, hipStream_t stream) {
+    if (tv.n_snps == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_simulate_exact, dim3(grid_blocks), dim3(512), 0, stream, tv.base, tv.row_stride_u,
+                       tv.plane_stride_u, tv.n_samples, tv.n_snps, seed, snp_global_begin, missing_q16, d_overflow);
+    return hipGetLastError();
+}
+
 // simulate_data.cpp:219-235: fair coin per sample, 1 = case, 0 = control
 __global__ void k_simulate_phenotype(uint64_t seed, u32x4 *mcase, u32x4 *mctrl, uint32_t units,
                                      uint32_t n_samples, uint32_t *counts2) {

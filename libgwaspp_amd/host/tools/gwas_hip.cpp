@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
         gd.updateGenotypeTable();
         HipGenotypeTable &ht = static_cast<HipGenotypeTable &>(*gd.getGenotypeTable());
         gw_table *h = ht.handle();
-        if (gw_table_simulate(h, sim_seed, 0, (uint32_t)sim_missing) != GW_OK || gw_table_simulate_phenotype(h, sim_seed) != GW_OK) {
+        if (gw_table_simulate_exact(h, sim_seed, 0, (uint32_t)sim_missing) != GW_OK || gw_table_simulate_phenotype(h, sim_seed) != GW_OK) {
             std::cerr << "simulate: " << gw_last_error() << std::endl;
             return 1;
         }

@@ -793,6 +793,68 @@ void gwo_sim_row_stream(uint64_t seed, uint64_t snp, const gwo_geom *g, uint32_t
     row[0] = (uint16_t)(0x7000 | (0u << 8) | (1u << 4) | 5u);
 }
 
+/* The generator with the reference simulator's exact allele count (data/simulate_data.cpp:191-205: exactly
+ * s = floor(p * 2N) 'B' alleles among the 2N alleles of a SNP, shuffled; consecutive alleles pair up into genotypes).
+ * A uniformly random arrangement = the s smallest of 2N independent random keys: allele `pos` gets a 32-bit key (one
+ * splitmix64 per sample for its two alleles) and the minor alleles are the s positions with the smallest (key, pos).
+ * Same rule as the device's k_simulate_exact, stated with a sort. */
+#define SIM_ALLELE_MUL 0x9FB21C651E98DF25ull
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+int gwo_sim_row_stream_exact(uint64_t seed, uint64_t snp, const gwo_geom *g, uint32_t missing_q16, uint16_t *row) {
+    const uint32_t n = g->n_samples;
+    memset(row, 0, (size_t)g->blocks_per_row * 2u);
+    uint64_t key = sim_snp_key(seed, snp);
+    uint32_t p_e5 = gwo_sim_snp_p_e5(seed, snp);
+    uint64_t s = ((uint64_t)p_e5 * 2ull * n) / 100000ull;   /* floor(p * 2N), simulate_data.cpp:193 */
+    uint64_t *e = (uint64_t *)malloc((size_t)2u * n * sizeof(uint64_t));
+    if (!e) return -1;
+    for (uint32_t c = 0; c < n; ++c) {
+        uint64_t h = splitmix64(key + SIM_ALLELE_MUL * (uint64_t)(c + 1u));
+        e[2u * c] = ((h >> 32) << 32) | (2u * c);
+        e[2u * c + 1u] = ((h & 0xFFFFFFFFull) << 32) | (2u * c + 1u);
+    }
+    uint64_t thr = 0;
+    if (s >= 1) {
+        uint64_t *sorted = (uint64_t *)malloc((size_t)2u * n * sizeof(uint64_t));
+        if (!sorted) { free(e); return -1; }
+        memcpy(sorted, e, (size_t)2u * n * sizeof(uint64_t));
+        qsort(sorted, (size_t)2u * n, sizeof(uint64_t), cmp_u64);
+        thr = sorted[s - 1];
+        free(sorted);
+    }
+    uint16_t *p0 = row + 1, *p1 = row + 1 + g->data_blocks;
+    for (uint32_t w = 0; w < g->words; ++w) {
+        uint32_t first = w * 64u;
+        uint64_t valid;
+        if (first >= n) valid = 0;
+        else if (n - first >= 64u) valid = ~0ull;
+        else valid = (1ull << (n - first)) - 1ull;
+        uint64_t m1 = 0, m2 = 0;
+        for (uint32_t bit = 0; bit < 64u && first + bit < n; ++bit) {
+            uint32_t c = first + bit;
+            m1 |= (uint64_t)(s >= 1 && e[2u * c] <= thr) << bit;
+            m2 |= (uint64_t)(s >= 1 && e[2u * c + 1u] <= thr) << bit;
+        }
+        uint64_t a = ~(m1 ^ m2), b = m1 | m2;
+        if (missing_q16) {
+            uint64_t wkey = key + SIM_WORD_MUL * (uint64_t)(w + 1);
+            uint64_t miss = bernoulli64(wkey, 32, missing_q16);
+            a &= ~miss;
+            b &= ~miss;
+        }
+        a &= valid;
+        b &= valid;
+        memcpy(p0 + 4 * w, &a, 8);
+        memcpy(p1 + 4 * w, &b, 8);
+    }
+    free(e);
+    row[0] = (uint16_t)(0x7000 | (0u << 8) | (1u << 4) | 5u);
+    return 0;
+}
+
 void gwo_sim_phenotype_stream(uint64_t seed, const gwo_geom *g, uint16_t *cs, uint16_t *ct,
                               uint32_t *case_count, uint32_t *ctrl_count) {
     uint32_t nc = 0, nt = 0;

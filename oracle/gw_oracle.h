@@ -204,6 +204,8 @@ void gwo_scan_stream_cc_mt(const uint16_t *table, uint32_t n_snps, const gwo_geo
 void gwo_sim_row_stream(uint64_t seed, uint64_t snp, const gwo_geom *g, uint32_t missing_q16,
                         uint16_t *row);
 /* phenotype masks (simulate_data.cpp:219-235: fair coin per sample). */
+/* exact minor-allele count per SNP, as simulate_data.cpp:191-205 (0 on success) */
+int gwo_sim_row_stream_exact(uint64_t seed, uint64_t snp, const gwo_geom *g, uint32_t missing_q16, uint16_t *row);
 void gwo_sim_phenotype_stream(uint64_t seed, const gwo_geom *g,
                               uint16_t *case_stream, uint16_t *ctrl_stream,
                               uint32_t *case_count, uint32_t *ctrl_count);

@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         L.gwo_scan_block_cc.argtypes = L.gwo_scan_stream_cc.argtypes
         L.gwo_scan_stream_cc_mt.argtypes = L.gwo_scan_stream_cc.argtypes + [C.c_int]
         L.gwo_sim_row_stream.argtypes = [C.c_uint64, C.c_uint64, gp, C.c_uint32, u16p]
+        L.gwo_sim_row_stream_exact.argtypes = [C.c_uint64, C.c_uint64, gp, C.c_uint32, u16p]
         L.gwo_sim_phenotype_stream.argtypes = [C.c_uint64, gp, u16p, u16p, u32p, u32p]
         L.gwo_sim_snp_p_e5.argtypes = [C.c_uint64, C.c_uint64]
         L.gwo_sim_snp_p_e5.restype = C.c_uint32
@@ -352,11 +353,16 @@ def scan_block_cc(table, g, case_block, ctrl_block, case_count, ctrl_count, stat
 
 
 # ----------------------------------------------------------------- simulator
-def sim_table_stream(seed: int, snp_begin: int, n_snps: int, n: int, missing_q16: int = 0):
+def sim_table_stream(seed: int, snp_begin: int, n_snps: int, n: int, missing_q16: int = 0, exact: bool = False):
+    """exact=True: exactly floor(p * 2N) minor alleles per SNP (simulate_data.cpp:191-205) instead of binomial sampling"""
     g = geometry_stream(n)
     table = np.zeros((n_snps, g.blocks_per_row), dtype=np.uint16)
     for r in range(n_snps):
-        lib().gwo_sim_row_stream(seed, snp_begin + r, C.byref(g), missing_q16, _p16(table[r]))
+        if exact:
+            if lib().gwo_sim_row_stream_exact(seed, snp_begin + r, C.byref(g), missing_q16, _p16(table[r])) != 0:
+                raise MemoryError("gwo_sim_row_stream_exact")
+        else:
+            lib().gwo_sim_row_stream(seed, snp_begin + r, C.byref(g), missing_q16, _p16(table[r]))
     return table, g
 
 

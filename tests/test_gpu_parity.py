@@ -589,3 +589,40 @@ def test_deferred_records_auto_policy():
         assert np.array_equal(c_small, c[1000:51_000]) and np.array_equal(s_small, s[1000:51_000])
     with gw.GwTable(2_000, 100_000) as t:
         assert t.get_option(capi.OPT_DEFER_RECORDS) == 0
+
+
+# --------------------------------------------------------------------------
+# the exact-count generator (gw_table_simulate_exact): exactly floor(p * 2N) minor alleles per SNP in a random arrangement,
+# as data/simulate_data.cpp:191-205 produces by filling and shuffling; device rows == the oracle's restatement bit for bit
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,missing", [(1, 9, 0), (63, 20, 0), (64, 20, 655), (1000, 64, 0), (4097, 33, 655), (10_000, 40, 0),
+                                         (70_001, 6, 0)])
+def test_exact_count_generator_equals_the_oracle(oracle, n, m, missing):
+    seed, begin = 0xE7AC7, 123_456
+    with gw.GwTable(n, m) as t:
+        t.simulate(seed, begin, missing, exact=True)
+        rows = t.download_rows(0, m)
+        t.simulate(seed, begin, missing)                 # the binomial generator is another table
+        other = t.download_rows(0, m)
+    want, g = oracle.sim_table_stream(seed, begin, m, n, missing, exact=True)
+    assert np.array_equal(rows, want)
+    assert n < 64 or not np.array_equal(rows, other)
+    if not missing:                                      # the defining property, straight from the planes
+        nb = g.data_blocks
+        for r in range(m):
+            p0 = np.unpackbits(rows[r, 1:1 + nb].view(np.uint8), bitorder="little")[:n].astype(np.int64)
+            p1 = np.unpackbits(rows[r, 1 + nb:1 + 2 * nb].view(np.uint8), bitorder="little")[:n].astype(np.int64)
+            minor_alleles = int((p1 & (1 - p0)).sum() + 2 * (p0 & p1).sum())      # code 2: one, code 3: two
+            assert minor_alleles == oracle.sim_snp_p_e5(seed, begin + r) * 2 * n // 100000
+            assert int((p0 | p1).sum()) == n             # no missing call
+
+
+def test_exact_count_generator_at_full_row_length(oracle):
+    """500 000 samples (config 3's rows): sampled rows of a table generated by global index, against the oracle."""
+    n, m, seed = 500_000, 64, 0x5EED
+    with gw.GwTable(n, m) as t:
+        t.simulate(seed, 999_936, 0, exact=True)         # the last 64 SNPs of the 1 M-SNP job
+        rows = t.download_rows(0, m)
+    for r in (0, 17, 63):
+        want, _ = oracle.sim_table_stream(seed, 999_936 + r, 1, n, 0, exact=True)
+        assert np.array_equal(rows[r], want[0])

@@ -25,13 +25,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCE = os.path.join(ROOT, "libgwaspp_amd", "csrc", "gw_kernels.hip")
 BENCH = {"c3": ["--workload", "c3"], "c2": ["--workload", "c2"], "n10k": ["--workload", "n10k"],
-         "c1": ["--workload", "c1"]}
-SHAPES = {"c3": (500_000, 1_000_000), "c2": (100_000, 500_000), "n10k": (10_000, 1_000_000), "c1": (10_000, 50_000)}
+         "c1": ["--workload", "c1"], "c5": ["--workload", "c5"]}
+SHAPES = {"c3": (500_000, 1_000_000), "c2": (100_000, 500_000), "n10k": (10_000, 1_000_000), "c1": (10_000, 50_000),
+          "c5": (10_000, 100_000)}
+PREFIX = {"c5": "gw::k_boost"}  # the kernels of a workload (default: the scan's)
 
 
 def sha16():
-    with open(KERNEL_SOURCE, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.kernel_source_sha16()   # every kernel source of the library, one stamp
 
 
 def norm(name):
@@ -41,12 +44,12 @@ def norm(name):
     return name.split("(")[0]
 
 
-def scan_rows(path):
+def scan_rows(path, prefix="gw::k_scan_cc"):
     vals = {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             k = norm(row["Kernel_Name"])
-            if k.startswith("gw::k_scan_cc"):
+            if k.startswith(prefix):
                 vals.setdefault(k, []).append(float(row["Counter_Value"]))
     return vals
 
@@ -71,7 +74,7 @@ def run(workload):
         if not files:
             raise SystemExit("no counter_collection.csv under " + d)
         shutil.copy(files[0], os.path.join(out, counter + ".csv"))
-        vals = scan_rows(files[0])
+        vals = scan_rows(files[0], PREFIX.get(workload, "gw::k_scan_cc"))
         kernel = bench["roofline"]["kernel"]
         if kernel not in vals:
             raise SystemExit(f"kernel {kernel!r} not in the PMC file (has {sorted(vals)})")
@@ -84,6 +87,8 @@ def run(workload):
     entry["hbm_bytes_per_launch"] = 2.0 * entry["FETCH_SIZE_KB"] * 1024.0 + entry["WRITE_SIZE_KB"] * 1024.0
     entry["correction"] = ("gfx950: FETCH_SIZE counts 64 B per 128-B request of a 16-B/lane stream -> x2 "
                            "(MI355X_MICROARCH.md, HBM); KB -> x1024; WRITE_SIZE exact")
+    # c5 is bound by the matrix cores, not by HBM: its table (250 MB) is read M / 128 times over, mostly from L2 and the
+    # Infinity Cache; the entry records what reached HBM
     entry["algorithmic_bytes_per_launch"] = m * (n / 4.0)
     entry["kernel_source_sha16"] = sha16()
     entry["command"] = "rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra " + " ".join(BENCH[workload])
