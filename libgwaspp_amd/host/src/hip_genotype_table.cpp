@@ -37,7 +37,7 @@ inline void to_freq(const uint *c, frequency_table &ft) {
 
 HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
     : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
-      window(1u << 18), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), mar_begin(0), prefetch(true), installed(nullptr),
+      window(1u << 16), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), mar_begin(0), prefetch(true), installed(nullptr),
       installed_cases(0), installed_ctrls(0), check_every_call(false), row_cached(-1) {
     installed_sample[0] = installed_sample[1] = 0;
     initialize();

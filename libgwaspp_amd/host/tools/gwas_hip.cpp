@@ -269,7 +269,7 @@ int main(int argc, char **argv) {
                       "\"n_snps\": %d, \"scan_window_rows\": %d, \"walk_seconds_prefetch\": %.6f, "
                       "\"walk_seconds_no_prefetch\": %.6f, \"snps_per_s_prefetch\": %.1f, \"snps_per_s_no_prefetch\": %.1f, "
                       "\"kernel_ms\": %.6f, \"kernel_snps_per_s\": %.1f, \"kernel\": \"%s\", \"walk_equals_batch_scan\": %s}",
-                      N, M, scan_window > 0 ? scan_window : (1 << 18), walk[1], walk[0], M / walk[1], M / walk[0], ms / reps,
+                      N, M, scan_window > 0 ? scan_window : (1 << 16), walk[1], walk[0], M / walk[1], M / walk[0], ms / reps,
                       M / (ms / reps * 1e-3), gw_last_scan_kernel(h), same ? "true" : "false");
         *out << buf << std::endl;
         if (!same) return 3;
