@@ -52,6 +52,7 @@ WORKLOADS = {
     "c5": (10_000, 100_000, "c5: pairwise SNPxSNP epistasis, BOOST KSA pre-screen over 100k SNPs (10k samples)"),
 }
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the ~2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, matrix cores)
+MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4 / FP6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): 4x bf16 per clock (same table)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 0x5EED
 RECORD_BYTES = 32 + 64  # counts uint32[8] + stats float64[8] per SNP
@@ -369,10 +370,13 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
         # no missing calls in the synthetic table: 4 counted corners per pair and group, each a dot product
         # of 0/1 class vectors over the group's samples = n_samples MACs per corner -> int8 MFMA
         macs = n_pairs * 4.0 * n_samples
+        fp4 = "fp4" in kernel_name   # the kernel the dispatch recorded decides which matrix-core peak prices the run
+        peak = MFMA_FP4_PEAK_TOPS if fp4 else MFMA_I8_PEAK_TOPS
         out = {
             "metric": "SNP pairs/sec BOOST KSA pre-screen", "value": n_pairs / per_step, "unit": "pairs/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": per_step * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i8 x i8 -> i32 (counts), f64 (measure)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": ("fp4 (e2m1) x fp4 -> f32 (counts, exact), f64 (measure)" if fp4 else "i8 x i8 -> i32 (counts), f64 (measure)"),
             "data": "synthetic",
             "config": {"workload": ("REHEARSAL ON ONE GPU (gloo, host-staged exchange; not a measurement): " if rehearse else "") + text,
                        "n_samples": n_samples, "n_snps": n_snps, "pairs": n_pairs,
@@ -383,10 +387,12 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
                                     if (world > 1 or comm is not None) else "none"),
                        "rehearsal_union_equals_single_screen": rehearsal_ok,
                        "stats_dtype": "f64", "git": git_head()},
-            "roofline": {"bound": "mfma", "achieved": 2.0 * macs / per_step / 1e12, "peak": MFMA_I8_PEAK_TOPS,
-                         "unit": "TOP/s (int8, 2 ops per multiply-add; wall time of the whole screen incl. the "
-                                 "per-pair bound / measure epilogue and host round trips)",
-                         "frac": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS,
+            "roofline": {"bound": "mfma", "achieved": 2.0 * macs / per_step / 1e12, "peak": peak,
+                         "unit": "TOP/s (2 ops per multiply-add of a 0/1 class-vector dot product; wall time of the whole screen "
+                                 "incl. the per-pair bound / measure epilogue), peak = dense " +
+                                 ("FP4 MFMA (the operands are FP4: one sample per nibble)" if fp4 else "int8 MFMA"),
+                         "frac": 2.0 * macs / per_step / 1e12 / peak,
+                         "frac_of_int8_peak": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS,
                          "traffic": c5_traffic[0], "traffic_source": c5_traffic[1],
                          "kernel": kernel_name, "kernel_ms": kernel_ms_total / steps,
                          "launches_per_step": len(blocks),
@@ -773,7 +779,9 @@ def main():
                     e["algorithmic_bytes_per_launch"] = rf["algorithmic_bytes_per_launch"]
                 else:
                     e.update({"pairs": d["config"]["pairs"], "hits_over_30": d["config"]["hits_over_30"],
-                              "mfma_int8_TOPs": rf["achieved"], "cpu_baseline": d.get("cpu_baseline")})
+                              "mfma_TOPs": rf["achieved"], "peak_TOPs": rf["peak"],
+                              "frac_of_int8_peak": rf.get("frac_of_int8_peak"), "dtype": d["dtype"],
+                              "cpu_baseline": d.get("cpu_baseline")})
                 return e
             extra = {"c2": side("c2", args.steps, args.warmup, False),
                      "n10k": side("n10k", args.steps, args.warmup, False),

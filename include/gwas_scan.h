@@ -384,6 +384,10 @@ typedef enum gw_option {
                                 gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
                                 512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
                                 scan workgroup that has to wait for one finishes its static share of the rows late */
+    GW_OPT_BOOST_FP4 = 18,   /* pair screen, tables without a missing call and case groups < 65 536: 1 (default) the four corners
+                                counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 operands -- an operand dword carries 8
+                                samples (one per nibble) and an MFMA 64 per lane, twice the int8 form's, exact counts in
+                                FP32 accumulators (k_boost_mfma_fp4); 0 the int8 form (k_boost_mfma_seq<., 2, 2>) */
     GW_OPT_BOOST_LUT = 17,   /* pair screen of cohorts with at most 16 383 selected individuals and no missing call:
                                 1 = the persistent kernel whose single-precision bound looks its 27 logarithms up in an LDS
                                 table of k log2 k (k_boost_mfma_lut; an experiment of round 3: fewer vector instructions,

@@ -34,6 +34,7 @@ OPT_RESERVE_CUS = 14
 OPT_DEFER_RECORDS = 15
 OPT_BOOST_STAGGER_US = 16
 OPT_BOOST_LUT = 17
+OPT_BOOST_FP4 = 18
 
 
 class GwError(RuntimeError):

@@ -424,7 +424,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
                         float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name,
                         unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks, const float *d_klogk,
-                        uint32_t *d_park, int compute_units) {
+                        uint32_t *d_park, int compute_units, bool fp4) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -443,6 +443,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     };
     const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
     a.klogk = d_klogk; a.park = d_park;
+    a.fp4_scale[0] = 126; a.fp4_scale[1] = 127; a.fp4_scale[2] = 128;
     // small cohorts without a missing call: the persistent kernel with the bound's logarithms in an LDS table
     if (d_cct && d_marf && small_case_group && fast && pre && !d_dense && d_klogk && d_park && n_individs <= 16383u) {
         if (d_ticket && stagger_ticks) {  // one ticket counter per CU (4096 keys)
@@ -452,6 +453,11 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
         }
         note("gw::k_boost_mfma_lut%s", "", "");
         return launch_boost_mfma_lut4(a, compute_units, stream);
+    }
+    // the pair tables counted on FP4 operands (8 samples per operand dword, 64 per MFMA): four corners / nine cells
+    if (d_cct && d_marf && small_case_group && fp4) {
+        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2>" : "gw::k_boost_mfma_fp4<%s, 3, 1>", tp, "");
+        return launch_boost_mfma_fp4(a, pre, !fast, stream);
     }
     if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
         if (d_ticket && stagger_ticks && !d_dense) {

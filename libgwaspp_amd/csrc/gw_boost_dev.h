@@ -182,6 +182,7 @@ struct BoostArgs {
     const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
     float bound_threshold;      // PRE: the threshold rounded down to float; bound + err < this rules a pair out
     float lg_n;                 // PRE: log2(n_individs), rounded up (boost_bound_split's error bound)
+    int fp4_scale[3];           // k_boost_mfma_fp4: E8M0 block scales 2^-1, 2^0, 2^1 (126, 127, 128), as run-time values
     const float *klogk;         // k_boost_mfma_lut: k log2 k, k = 0 .. n_individs
     uint32_t *park;             // k_boost_mfma_lut: 64 KB per resident workgroup for the parked case counts
     // Start-up stagger of the one-group-at-a-time MFMA kernels: a workgroup's life is a matrix-core phase (counting)
@@ -247,5 +248,6 @@ hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stre
 hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
 hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
 hipError_t launch_boost_mfma_lut4(const BoostArgs &a, int compute_units, hipStream_t stream);     // gw_boost_lut4.hip
+hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream);    // gw_boost_fp4.hip
 
 }  // namespace gw

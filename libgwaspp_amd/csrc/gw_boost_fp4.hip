@@ -1,0 +1,289 @@
+// gw_boost_fp4.hip -- k_boost_mfma_fp4<PRE, NV, TA>: the pair kernels for case groups < 65 536 (four corners for tables
+// without a missing call, nine cells otherwise) with the pair tables counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 (E2M1) operands.
+//
+// k_boost_mfma_seq<PRE, 2, 2> (gw_boost_seq.inc) is bound by in-order issue: an int8 MFMA covers 32 samples per lane and
+// needs eight operand dwords made by one vector instruction each (4 samples per dword, one per byte) -- 25-27 of the
+// 32 cycles the matrix core takes go to issuing the MFMA and its operand expansion (profiles/r03_c5_experiments.txt).
+// FP4 halves both: an operand dword carries EIGHT samples, one per nibble, and one MFMA covers 64 per lane in the same
+// 32 cycles.  The expansion stays a single v_and / v_bitop3: dword = class word & (0x11111111 << k) leaves the FP4 values
+// 0.5 (k = 0), 1 (k = 1), 2 (k = 2) in the nibbles; k = 3 would be the sign bit, so that one is (word >> 3) & 0x11111111
+// (0.5).  No bit reversal on the B side: all four dwords of an operand use the SAME k (one dword from each of four words,
+// i.e. two 64-sample units = two chunks of the block-tiled table per MFMA), so every product of an MFMA carries the same
+// weight 4^(k-1), and the instruction's own E8M0 block scales (byte 0 of a VGPR per operand: 128 / 127 / 126 = 2 / 1 /
+// 0.5) put it back to exactly 1.  Accumulators are FP32 and hold the counts exactly (< 2^24).  tools/fp4_probe.hip is the
+// 32 x 32 x 256 check of all of this against popcounts.
+// Per pair of chunks (256 samples per row): 32 MFMAs (64 before) and 120 expansion instructions (264 before).
+// Everything else -- one group at a time, the case counts parked in LDS as uint16, the per-pair split-log bound and the
+// FP64 measure -- is k_boost_mfma_seq's; hits and measures are bit-identical.
+#include "gw_boost_dev.h"
+
+namespace gw {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// NV = 2, TA = 2: the four corners on 64 x 32 pairs per wave (tables without a missing call);
+// NV = 3, TA = 1: all nine cells on 32 x 32 pairs per wave (tables with missing calls), as k_boost_mfma_seq<., 3, 1>
+template <bool PRE, int NV, int TA>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
+    constexpr int NP = NV * NV;            // products per tile pair
+    constexpr int NT = TA * NP;            // accumulator tiles
+    constexpr int WA = 32 * TA;            // A rows per wave
+    __shared__ uint32_t s_case[NT * 8 * 256];  // [tile][register pair][thread]: two uint16 case counts
+
+    const uint32_t a0 = a.a_begin + blockIdx.y * (2 * WA), b0 = a.b_begin + blockIdx.x * MT;
+    const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
+    if (a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t wy = wave >> 1, wx = wave & 1u;
+    const uint32_t fr = lane & 31u, fh = lane >> 5;
+
+    const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;  // both multiples of 8
+    auto unit = [&](uint32_t snp) {
+        return a.cct + ((uint64_t)(snp >> 6) * nchunk * 64u + (snp & 63u)) * 2u + fh;
+    };
+    const u32x4 *ga[TA];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) ga[ta] = unit(min(a0 + wy * WA + ta * 32u + fr, a_end - 1u));
+    const u32x4 *gb = unit(min(b0 + wx * 32u + fr, b_end - 1u));
+
+    f32x16 acc[TA][NP];  // [A tile][2 * class of A + class of B], one group at a time; exact counts
+    auto clear = [&]() {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int c = 0; c < NP; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ta][c][r] = 0.0f;
+    };
+    clear();
+
+    constexpr int RING = 4;  // chunks in flight per operand row (two MFMA groups of two chunks)
+    u32x4 ua[RING][TA], ub[RING];
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) ua[k][ta] = ga[ta][(uint64_t)k * 128u];
+        ub[k] = gb[(uint64_t)k * 128u];
+    }
+    const uint32_t last_chunk = nchunk - 1u;
+    // E8M0 block scales, byte 0 of a VGPR each (run-time values: a compile-time constant would be taken for an f32)
+    const int sc_half = a.fp4_scale[0], sc_one = a.fp4_scale[1], sc_two = a.fp4_scale[2];
+
+    // class c of word w (0, 1) of a 64-sample unit {plane0 w0, plane0 w1, plane1 w0, plane1 w1}: NV = 2: aa, bb;
+    // NV = 3: aa, ab, bb (plane0 = codes 1, 3; plane1 = codes 2, 3)
+    auto cls = [](const u32x4 &v, int c, int w) -> uint32_t {
+        const uint32_t p0 = v[w], p1 = v[2 + w];
+        if (c == 0) return p0 & ~p1;
+        if (c == NV - 1) return p0 & p1;
+        return p1 & ~p0;
+    };
+    // operand: sample k of every nibble of four words (two units); k = 3 is the FP4 sign bit and goes through a shift
+    auto expand = [](const uint32_t (&w)[4], int k) -> i32x8 {
+        i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k < 3 ? (int)(w[j] & (0x11111111u << k)) : (int)((w[j] >> 3) & 0x11111111u);
+        return v;
+    };
+    auto chunk_pair = [&](const u32x4 (&va0)[TA], const u32x4 (&va1)[TA], const u32x4 &vb0, const u32x4 &vb1) {
+        uint32_t ca[TA][NV][4], cb[NV][4];
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                for (int ta = 0; ta < TA; ++ta) {
+                    ca[ta][c][w] = cls(va0[ta], c, w);
+                    ca[ta][c][2 + w] = cls(va1[ta], c, w);
+                }
+                cb[c][w] = cls(vb0, c, w);
+                cb[c][2 + w] = cls(vb1, c, w);
+            }
+        static_for<0, 4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const int sc = k == 1 ? sc_one : (k == 2 ? sc_half : sc_two);  // values 1 / 2 / 0.5 (k = 0, 3) -> products of 1
+            i32x8 xa[TA][NV], yb[NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+#pragma unroll
+                for (int ta = 0; ta < TA; ++ta) xa[ta][c] = expand(ca[ta][c], k);
+                yb[c] = expand(cb[c], k);
+            }
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+                for (int x = 0; x < NV; ++x)
+#pragma unroll
+                    for (int y = 0; y < NV; ++y)
+                        acc[ta][NV * x + y] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            xa[ta][x], yb[y], acc[ta][NV * x + y], 4, 4, 0, sc, 0, sc);  // cbsz = blgp = 4: FP4 E2M1
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (32 cycles)
+                __builtin_amdgcn_sched_group_barrier(0x002, NV == 3 ? 3 : 4, 0);  // its share of the VALU
+            }
+        });
+    };
+    auto round = [&](uint32_t c0) {  // RING = 4 chunks = two MFMA groups
+        static_for<0, RING / 2>([&](auto kc) {
+            constexpr int k = 2 * decltype(kc)::value;
+            chunk_pair(ua[k], ua[k + 1], ub[k], ub[k + 1]);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const uint64_t nxt = (uint64_t)min(c0 + k + d + RING, last_chunk) * 128u;  // past the end: re-read, unused
+#pragma unroll
+                for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
+                ub[k + d] = gb[nxt];
+            }
+        });
+    };
+    for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                s_case[((ta * NP + c) * 8 + (r >> 1)) * 256 + t] = (uint32_t)acc[ta][c][r] | ((uint32_t)acc[ta][c][r + 1] << 16);
+    clear();
+    for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
+
+    // ---- per pair (C layout as in k_boost_mfma); pair p = 16 ta + reg
+    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * WA + 4u * fh;
+    const bool j_ok = j < b_end;
+    const SnpMargin *pm2 = a.mar + (j_ok ? j : b_end - 1u);
+    uint32_t f2c[3], f2t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f2c[k] = pm2->cases[k]; f2t[k] = pm2->ctrls[k]; }
+    SnpMarginF mf2;
+    if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
+    const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
+    // NV == 2 <=> the table has no missing call: the bound with the logarithms split (boost_bound_split)
+    const float lg_n = a.lg_n;  // >= log2 n (rounded up on the host)
+    auto bound_of = [&](const uint32_t (&ca)[9], const uint32_t (&co)[9], const SnpMarginF &f1, float &err) -> float {
+        if constexpr (NV == 2) return boost_bound_split(ca, co, f1, mf2, nf, lg_n, err);
+        else return boost_bound(ca, co, f1, mf2, nf, inv_n, err);
+    };
+    auto case_count = [&](int tile, int r) -> uint32_t {  // r may be a run-time value
+        const uint32_t v = s_case[(tile * 8 + (r >> 1)) * 256 + t];
+        return (r & 1) ? v >> 16 : v & 0xFFFFu;
+    };
+    auto row_of = [&](int p) { return i_base + (uint32_t)((p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2)); };
+    // the two 3 x 3 tables of a pair from its counted cells (cells[0] cases, [1] controls)
+    auto tables = [&](const uint32_t (&cells)[2][NP], const uint32_t *f1c, const uint32_t *f1t, uint32_t (&ca)[9],
+                      uint32_t (&co)[9]) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint32_t *o = g == 0 ? ca : co;
+            if (NV == 3) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = cells[g][c % NP];
+            } else {  // table5.cpp:1088-1106 / 1125-1143: corners counted, the rest from the margins
+                const uint32_t *f1 = g == 0 ? f1c : f1t;
+                const uint32_t *f2 = g == 0 ? f2c : f2t;
+                o[0] = cells[g][0]; o[2] = cells[g][1]; o[6] = cells[g][2 % NP]; o[8] = cells[g][3 % NP];
+                o[1] = f1[0] - o[0] - o[2];
+                o[7] = f1[2] - o[8] - o[6];
+                o[3] = f2[0] - o[0] - o[6];
+                o[5] = f2[2] - o[2] - o[8];
+                o[4] = f2[1] - o[1] - o[7];
+            }
+        }
+    };
+
+    uint32_t need = 0;
+    unsigned long long n_eval = 0;
+    static_for<0, 16 * TA>([&](auto pc) {
+        constexpr int p = decltype(pc)::value, ta = p >> 4, r = p & 15;
+        const uint32_t i = row_of(p);
+        if (i < a_end && j_ok && i < j) {
+            ++n_eval;
+            if (PRE) {
+                uint32_t cells[2][NP], ca[9], co[9];
+#pragma unroll
+                for (int c = 0; c < NP; ++c) {
+                    cells[0][c] = case_count(ta * NP + c, r);
+                    cells[1][c] = (uint32_t)acc[ta][c][r];
+                }
+                const SnpMargin *pm1 = a.mar + i;
+                tables(cells, pm1->cases, pm1->ctrls, ca, co);
+                float err;
+                const float bound = bound_of(ca, co, a.marf[i], err);
+                if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)(a.dense_err ? err : bound);
+                else if (!bound_rules_out(bound, err, a.bound_threshold)) need |= 1u << p;
+            } else {
+                need |= 1u << p;
+            }
+        }
+    });
+
+    double vmax = -1.0e300, vmin = 1.0e300;
+    while (need) {
+        const int p = __ffs((int)need) - 1;
+        need &= need - 1u;
+        uint32_t cells[2][NP], ca[9], co[9];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            uint32_t y = 0;
+#pragma unroll
+            for (int q = 0; q < 16 * TA; ++q) y = p == q ? (uint32_t)acc[q >> 4][c][q & 15] : y;
+            cells[0][c] = case_count((p >> 4) * NP + c, p & 15);
+            cells[1][c] = y;
+        }
+        const uint32_t i = row_of(p);
+        const SnpMargin m1 = a.mar[i], m2 = *pm2;
+        tables(cells, m1.cases, m1.ctrls, ca, co);
+        const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
+        if (!PRE) {
+            vmax = fmax(vmax, measure);
+            vmin = fmin(vmin, measure);
+        } else if (!a.dense) {  // few pairs get here: the bound again, checked against the measure
+            float err;
+            const float bound = bound_of(ca, co, a.marf[i], err);
+            check_bound(measure, bound, err, a.tally);
+        }
+        if (measure > a.threshold) {  // :482-484
+            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+            if (slot < a.max_hits) {
+                BoostHit h;
+                h.snp_a = i;
+                h.snp_b = j;
+                h.measure = measure;
+                a.hits[slot] = h;
+            }
+        }
+        if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_eval += __shfl_xor(n_eval, off, 64);
+        if (!PRE) {
+            vmax = fmax(vmax, __shfl_xor(vmax, off, 64));
+            vmin = fmin(vmin, __shfl_xor(vmin, off, 64));
+        }
+    }
+    if (lane == 0 && n_eval) {
+        atomicAdd(&a.tally[1], n_eval);
+        if (!PRE) {
+            atomicMax(&a.tally[2], ordered(vmax));
+            atomicMin(&a.tally[3], ordered(vmin));
+        }
+    }
+}
+
+
+hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream) {
+    if (nine) {
+        const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1>), grid, dim3(256), 0, stream, a);
+    } else {
+        const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + 2 * MT - 1) / (2 * MT));
+        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 2, 2>), grid, dim3(256), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gw

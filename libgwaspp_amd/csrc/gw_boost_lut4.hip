@@ -23,6 +23,9 @@
 
 namespace gw {
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 namespace {
 constexpr int LUT_TA = 2, LUT_NT = 8;               // 2 A tiles x 4 corners
 constexpr uint32_t PARK_DWORDS = LUT_NT * 8u * 256u;  // [tile][register pair][thread]: two uint16 (4 x count) each
@@ -120,14 +123,14 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
         for (int ta = 0; ta < LUT_TA; ++ta) ga[ta] = unit(min(a0 + wy * 64u + ta * 32u + fr, a_end - 1u));
         const u32x4 *gb = unit(min(b0 + wx * 32u + fr, b_end - 1u));
 
-        i32x16 acc[LUT_TA][4];
+        f32x16 acc[LUT_TA][4];  // exact counts (FP4 operands, see gw_boost_fp4.hip)
         auto clear = [&]() {
 #pragma unroll
             for (int ta = 0; ta < LUT_TA; ++ta)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[ta][c][r] = 0;
+                    for (int r = 0; r < 16; ++r) acc[ta][c][r] = 0.0f;
         };
         clear();
         constexpr int RING = 4;
@@ -138,32 +141,40 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
             for (int ta = 0; ta < LUT_TA; ++ta) ua[k][ta] = ga[ta][(uint64_t)k * 128u];
             ub[k] = gb[(uint64_t)k * 128u];
         }
-        // (the class words are not precomputed: v_bitop3_b32 folds "p0 & ~p1 & mask" into the one instruction the
-        // expansion needs anyway, and two more 250 MB copies of the table would not fit the Infinity Cache -- tried,
-        // 135 vs 123 ms)
+        const int sc_half = a.fp4_scale[0], sc_one = a.fp4_scale[1], sc_two = a.fp4_scale[2];
         auto cls = [](const u32x4 &v, int c, int w) -> uint32_t {  // aa / bb of word w
             const uint32_t p0 = v[w], p1 = v[2 + w];
             return c == 0 ? (p0 & ~p1) : (p0 & p1);
         };
-        auto chunk = [&](const u32x4 (&va)[LUT_TA], const u32x4 &vb) {
-            uint32_t ca[LUT_TA][2][2], cb[2][2], rb[2][2];
+        auto expand = [](const uint32_t (&w)[4], int k) -> i32x8 {  // gw_boost_fp4.hip: sample k of every nibble of four words
+            i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int w = 0; w < 2; ++w)
+            for (int j = 0; j < 4; ++j) v[j] = k < 3 ? (int)(w[j] & (0x11111111u << k)) : (int)((w[j] >> 3) & 0x11111111u);
+            return v;
+        };
+        auto chunk_pair = [&](const u32x4 (&va0)[LUT_TA], const u32x4 (&va1)[LUT_TA], const u32x4 &vb0, const u32x4 &vb1) {
+            uint32_t ca[LUT_TA][2][4], cb[2][4];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int ta = 0; ta < LUT_TA; ++ta) ca[ta][c][w] = cls(va[ta], c, w);
-                    cb[c][w] = cls(vb, c, w);
-                    rb[c][w] = __builtin_bswap32(__builtin_bitreverse32(cb[c][w])) >> 1;
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int ta = 0; ta < LUT_TA; ++ta) {
+                        ca[ta][c][w] = cls(va0[ta], c, w);
+                        ca[ta][c][2 + w] = cls(va1[ta], c, w);
+                    }
+                    cb[c][w] = cls(vb0, c, w);
+                    cb[c][2 + w] = cls(vb1, c, w);
                 }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                i32x4 xa[LUT_TA][2], yb[2];
+            static_for<0, 4>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int sc = k == 1 ? sc_one : (k == 2 ? sc_half : sc_two);
+                i32x8 xa[LUT_TA][2], yb[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                    for (int ta = 0; ta < LUT_TA; ++ta) xa[ta][c] = expand_a(ca[ta][c][s >> 1], s & 1);
-                    yb[c] = expand_b(cb[c][s >> 1], rb[c][s >> 1], s & 1);
+                    for (int ta = 0; ta < LUT_TA; ++ta) xa[ta][c] = expand(ca[ta][c], k);
+                    yb[c] = expand(cb[c], k);
                 }
 #pragma unroll
                 for (int ta = 0; ta < LUT_TA; ++ta)
@@ -171,27 +182,30 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
                     for (int x = 0; x < 2; ++x)
 #pragma unroll
                         for (int yy = 0; yy < 2; ++yy)
-                            acc[ta][2 * x + yy] =
-                                __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[ta][x], yb[yy], acc[ta][2 * x + yy], 0, 0, 0);
+                            acc[ta][2 * x + yy] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                xa[ta][x], yb[yy], acc[ta][2 * x + yy], 4, 4, 0, sc, 0, sc);
 #pragma unroll
                 for (int m = 0; m < LUT_NT; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA (32 cycles)
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // its share of the VALU
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // its share of the VALU
                 }
-            }
+            });
         };
         auto round = [&](uint32_t c0) {
-            static_for<0, RING>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                chunk(ua[k], ub[k]);
-                const uint64_t nxt = (uint64_t)min(c0 + k + RING, last_chunk) * 128u;  // past the end: re-read, unused
+            static_for<0, RING / 2>([&](auto kc) {
+                constexpr int k = 2 * decltype(kc)::value;
+                chunk_pair(ua[k], ua[k + 1], ub[k], ub[k + 1]);
 #pragma unroll
-                for (int ta = 0; ta < LUT_TA; ++ta) ua[k][ta] = ga[ta][nxt];
-                ub[k] = gb[nxt];
+                for (int d = 0; d < 2; ++d) {
+                    const uint64_t nxt = (uint64_t)min(c0 + k + d + RING, last_chunk) * 128u;  // past the end: re-read, unused
+#pragma unroll
+                    for (int ta = 0; ta < LUT_TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
+                    ub[k + d] = gb[nxt];
+                }
             });
         };
         for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
-        // the case counts leave the registers: 4 x count (acc = 64 x count) of two accumulator registers per dword
+        // the case counts leave the registers: 4 x count of two accumulator registers per dword
 #pragma unroll
         for (int ta = 0; ta < LUT_TA; ++ta)
 #pragma unroll
@@ -199,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2)
                     __builtin_amdgcn_raw_buffer_store_b32(
-                        ((uint32_t)acc[ta][c][r] >> 4) | (((uint32_t)acc[ta][c][r + 1] >> 4) << 16), park, t4,
+                        ((uint32_t)acc[ta][c][r] << 2) | (((uint32_t)acc[ta][c][r + 1] << 2) << 16), park, t4,
                         ((ta * 4 + c) * 8 + (r >> 1)) * 1024, 0);
         clear();
         for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
@@ -299,7 +313,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
                     for (int c = 0; c < 4; ++c) {
                         const uint32_t v = pk[q % (AHEAD + 1)][c];
                         c4[0][c] = (r & 1) ? v >> 16 : v & 0xFFFFu;
-                        c4[1][c] = (uint32_t)acc[ta][c][r] >> 4;
+                        c4[1][c] = (uint32_t)acc[ta][c][r] << 2;
                     }
                     uint32_t f1c4[3], f1t4[3];
                     RowF f1;
@@ -326,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_lut(BoostArgs a) {
                 for (int q = 0; q < 16 * LUT_TA; ++q) yv = p == q ? (uint32_t)acc[q >> 4][c][q & 15] : yv;
                 const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(park, t4, (((p >> 4) * 4 + c) * 8 + ((p & 15) >> 1)) * 1024, 0);
                 c4[0][c] = (p & 1) ? v >> 16 : v & 0xFFFFu;
-                c4[1][c] = yv >> 4;
+                c4[1][c] = yv << 2;
             }
             const uint32_t i = row_of(p);
             const SnpMargin m1 = a.mar[i], m2 = *pm2;

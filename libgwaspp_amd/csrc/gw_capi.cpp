@@ -98,7 +98,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0, opt_boost_fp4 = 1;
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -1036,7 +1036,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
                                 t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3,
                                 t->last_boost_kernel, reinterpret_cast<unsigned int *>(t->d_tally + 4),
                                 (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t),
-                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units);
+                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0);
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1121,7 +1121,7 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
                             tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
                             t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel,
                             reinterpret_cast<unsigned int *>(t->d_tally + 4), (uint32_t)t->compute_units * 2u,
-                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units));
+                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0));
     return GW_OK;
 }
 
@@ -1338,6 +1338,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
     case GW_OPT_BOOST_LUT:
         t->opt_boost_lut = v ? 1 : 0;
         return GW_OK;
+    case GW_OPT_BOOST_FP4:
+        t->opt_boost_fp4 = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_BOOST_STAGGER_US:
         if (v < -1 || v > 100000) return fail(GW_E_INVALID, "boost_stagger_us must be -1 (auto), 0 (off) or microseconds");
         t->opt_boost_stagger = (int)v;
@@ -1386,6 +1389,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_DEFER_RECORDS: *v = sh.defer; return GW_OK;
     case GW_OPT_BOOST_STAGGER_US: *v = boost_stagger_ticks(t) / 100u; return GW_OK;
     case GW_OPT_BOOST_LUT: *v = t->opt_boost_lut; return GW_OK;
+    case GW_OPT_BOOST_FP4: *v = t->opt_boost_fp4; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

@@ -159,7 +159,9 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         unsigned int *d_ticket = nullptr, uint32_t first_gen = 0, uint32_t stagger_ticks = 0,
                         // k_boost_mfma_lut (cohorts of at most 16 383 without a missing call): k log2 k for
                         // k = 0 .. n_individs, boost_lut_park_bytes() of scratch, the device's CU count; null = not used
-                        const float *d_klogk = nullptr, uint32_t *d_park = nullptr, int compute_units = 0);
+                        const float *d_klogk = nullptr, uint32_t *d_park = nullptr, int compute_units = 0,
+                        // four-corner tables counted on FP4 operands (k_boost_mfma_fp4) instead of int8 ones
+                        bool fp4 = false);
 hipError_t launch_boost_klogk(uint32_t n_entries, float *d_klogk, hipStream_t stream);
 size_t boost_lut_park_bytes(int compute_units);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32

@@ -303,6 +303,7 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
         for thr in (30.0, 6.0, -1.0e9):
             for (a, na, b, nb) in calls:
                 t.set_option(gw.capi.OPT_BOOST_LUT, 0)
+                t.set_option(gw.capi.OPT_BOOST_FP4, 0)
                 want, wh, wp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
                 k0 = t.last_boost_kernel()
                 t.set_option(gw.capi.OPT_BOOST_LUT, 1)
@@ -310,6 +311,13 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
                 assert k0.startswith("gw::k_boost_mfma_seq<true, 2, 2") and t.last_boost_kernel() == "gw::k_boost_mfma_lut"
                 assert (gh, gp) == (wh, wp)
                 assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
+                # ... and the default: the four corners counted on FP4 operands
+                t.set_option(gw.capi.OPT_BOOST_LUT, 0)
+                t.set_option(gw.capi.OPT_BOOST_FP4, 1)
+                got4, gh4, gp4, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
+                assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2>"
+                assert (gh4, gp4) == (wh, wp)
+                assert np.array_equal(np.sort(got4, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
         assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
     # a table with missing calls, or a cohort above 16 383, never takes it
     with gw.GwTable(2000, 100) as t:
@@ -317,4 +325,27 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
         t.simulate_phenotype(11)
         t.set_option(gw.capi.OPT_BOOST_LUT, 1)
         t.boost_screen(0, 100, 0, 100, extremes=False)
-        assert t.last_boost_kernel().startswith("gw::k_boost_mfma_seq<true, 3, 1")
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1>"   # nine cells: never the LUT form
+
+
+@pytest.mark.parametrize("missing", [0, 655])
+@pytest.mark.parametrize("n,m", [(300, 70), (2000, 300), (20_000, 257), (70_000, 130)])
+def test_fp4_counting_equals_int8_counting(n, m, missing):
+    """k_boost_mfma_fp4 (v_mfma_scale_f32_32x32x64_f8f6f4 on one-sample-per-nibble operands, E8M0 scales 2 / 1 / 0.5) against
+    the int8 kernel and the vector-ALU kernel: every pair's FP64 measure (the dense form runs every pair through the
+    counted tables), extremes, hit lists -- bit-identical, for cohorts on both sides of every padding boundary."""
+    with gw.GwTable(n, m) as t:
+        t.simulate(23, 9, missing, exact=True)        # with missing calls: the nine-cell kernels
+        t.simulate_phenotype(23)
+        res = {}
+        for name, (fp4, mfma) in {"fp4": (1, 1), "int8": (0, 1), "valu": (0, 0)}.items():
+            t.set_option(gw.capi.OPT_BOOST_FP4, fp4)
+            t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mfma)
+            dense = t.boost_measures(0, m, 0, m)
+            hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=8.0)
+            res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin, t.last_boost_kernel())
+        shape = "3, 1" if missing else "2, 2"
+        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
+        for other in ("int8", "valu"):
+            assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
+            assert np.array_equal(res["fp4"][1], res[other][1]) and res["fp4"][2:6] == res[other][2:6]

@@ -19,11 +19,15 @@ ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--missing-q16", type=int, default=0)
 ap.add_argument("--us", default="0,20,35,50,65,80")
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--lut", type=int, default=0, help="GW_OPT_BOOST_LUT")
+ap.add_argument("--fp4", type=int, default=1, help="GW_OPT_BOOST_FP4")
 args = ap.parse_args()
 m, n = args.snps, args.samples
 t = gw.GwTable(n, m)
 t.simulate(0x5EED, 0, args.missing_q16)
 t.simulate_phenotype(0x5EED)
+t.set_option(capi.OPT_BOOST_LUT, args.lut)
+t.set_option(capi.OPT_BOOST_FP4, args.fp4)
 t.boost_screen(0, min(m, 64), 0, min(m, 64))
 cap = 1 << 18
 lst = capi.DeviceBuffer(capi.BOOST_LIST_HEADER_BYTES + 16 * cap)
