@@ -194,6 +194,8 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
 
     uint32_t need = 0;
     unsigned long long n_eval = 0;
+    // (the bound for two pairs at a time with packed FP32 multiply-adds -- 213 instead of 253 instructions per pair -- was
+    // measured slower, 84.5 vs 82.8 ms in alternating processes on one box: profiles/r03_c5_experiments.txt)
     static_for<0, 16 * TA>([&](auto pc) {
         constexpr int p = decltype(pc)::value, ta = p >> 4, r = p & 15;
         const uint32_t i = row_of(p);
