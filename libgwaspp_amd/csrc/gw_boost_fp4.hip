@@ -59,7 +59,10 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     };
     clear();
 
-    constexpr int RING = 4;  // chunks in flight per operand row (two MFMA groups of two chunks)
+#ifndef GW_FP4_RING
+#define GW_FP4_RING 4
+#endif
+    constexpr int RING = GW_FP4_RING;  // chunks in flight per operand row (MFMA groups of two chunks each)
     u32x4 ua[RING][TA], ub[RING];
 #pragma unroll
     for (int k = 0; k < RING; ++k) {
@@ -201,7 +204,11 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
         const uint32_t i = row_of(p);
         if (i < a_end && j_ok && i < j) {
             ++n_eval;
+#ifdef GW_FP4_NO_BOUND   // measurement only (tools/build_variant_file.sh): the launch without any per-pair work
+            if (a.n_individs < 0) {
+#else
             if (PRE) {
+#endif
                 uint32_t cells[2][NP], ca[9], co[9];
 #pragma unroll
                 for (int c = 0; c < NP; ++c) {
@@ -215,7 +222,9 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
                 if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)(a.dense_err ? err : bound);
                 else if (!bound_rules_out(bound, err, a.bound_threshold)) need |= 1u << p;
             } else {
+#ifndef GW_FP4_NO_BOUND
                 need |= 1u << p;
+#endif
             }
         }
     });
