@@ -626,3 +626,27 @@ def test_exact_count_generator_at_full_row_length(oracle):
     for r in (0, 17, 63):
         want, _ = oracle.sim_table_stream(seed, 999_936 + r, 1, n, 0, exact=True)
         assert np.array_equal(rows[r], want[0])
+
+
+def test_new_table_reads_as_unknown_everywhere_without_a_create_time_memset(oracle):
+    """gw_table_create no longer zero-fills (a table that is generated in place never pays the 20 ms for 125 GB); the fill
+    happens at the first use that does not overwrite the whole table.  Every reader must still see 'unknown' everywhere
+    (table5.cpp:82-83), whatever comes first: a scan, a download, a partial upload, a pair table."""
+    n, m = 1000, 50
+    rng = np.random.default_rng(4)
+    row7 = oracle.pack_codes(_random_codes(rng, 1, n, p_missing=0.1), "stream")
+    with gw.GwTable(n, m) as t:                       # first use: a distribution scan
+        assert np.array_equal(t.scan_distribution(), np.tile(np.array([0, 0, 0, n], np.uint32), (m, 1)))
+    with gw.GwTable(n, m) as t:                       # first use: a partial upload
+        t.upload_rows(7, row7)
+        rows = t.download_rows(0, m)
+        assert np.array_equal(rows[7, 1:], row7[0, 1:]) and not rows[:7, 1:].any() and not rows[8:, 1:].any()
+    with gw.GwTable(n, m) as t:                       # first use: a download
+        assert not t.download_rows(0, m)[:, 1:].any()
+    with gw.GwTable(n, m) as t:                       # first use: a pair table (every sample missing at both markers)
+        tab = t.pair_contingency([(0, 1), (3, 49)])
+        assert np.array_equal(tab[:, :15], np.zeros((2, 15), np.uint32)) and np.all(tab[:, 15] == oracle.geometry_stream(n).words * 64)
+    with gw.GwTable(n, m) as t:                       # generated in place, then read: nothing of the old contents, no fill
+        t.simulate(9, 0, 0, exact=True)
+        d = t.scan_distribution()
+        assert np.all(d[:, 3] == 0) and np.all(d[:, :3].sum(axis=1) == n)
