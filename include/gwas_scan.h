@@ -361,7 +361,8 @@ typedef enum gw_option {
                                 libgwaspp_amd/csrc/gw_boost_dev.h: ~6e-8 * (145 n + 30 |s| + ...), 0.09 at
                                 n = 10 k), and run the FP64 measure only where bound + err >= threshold -- the hit
                                 list and its FP64 measures are those of the all-FP64 screen; 0 never;
-                                2 / 3 diagnostic: gw_boost_measures returns the bound / its error bound */
+                                2 / 3 diagnostic: gw_boost_measures returns the bound / its error bound
+                                (4 / 5: those of the first level, GW_OPT_BOOST_FIRST_LEVEL) */
     GW_OPT_BOOST_PREFILTER_TRIPS = 12, /* get: how many pre-filtered screens of this handle found a pair whose FP64
                                 measure lay outside [bound - err, bound + err] (the error model's assumptions on
                                 v_log_f32 / v_rcp_f32 failing) and were therefore repeated with every pair in
@@ -388,6 +389,13 @@ typedef enum gw_option {
                                 counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 operands -- an operand dword carries 8
                                 samples (one per nibble) and an MFMA 64 per lane, twice the int8 form's, exact counts in
                                 FP32 accumulators (k_boost_mfma_fp4); 0 the int8 form (k_boost_mfma_seq<., 2, 2>) */
+    GW_OPT_BOOST_FIRST_LEVEL = 19, /* pre-filtered pair screen on the FP4 four-corner kernel: 1 (default) a logarithm-free
+                                upper bound of the measure first (the binary entropy of every cell replaced by a quadratic
+                                that lies below it: nine v_rcp_f32, a third of the vector work; measure <= bound1 + err1,
+                                derived in gw_boost_dev.h boost_bound_quad), the bound proper only for the ~3 pairs in
+                                10 000 it lets through, the FP64 measure for what passes both -- the hit list is that of
+                                the all-FP64 screen; 0 the bound proper for every pair.  GW_OPT_BOOST_PREFILTER 4 / 5
+                                (diagnostic): gw_boost_measures returns the first-level bound / its error bound */
     GW_OPT_BOOST_LUT = 17,   /* pair screen of cohorts with at most 16 383 selected individuals and no missing call:
                                 1 = the persistent kernel whose single-precision bound looks its 27 logarithms up in an LDS
                                 table of k log2 k (k_boost_mfma_lut; an experiment of round 3: fewer vector instructions,

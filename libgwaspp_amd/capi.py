@@ -35,6 +35,7 @@ OPT_DEFER_RECORDS = 15
 OPT_BOOST_STAGGER_US = 16
 OPT_BOOST_LUT = 17
 OPT_BOOST_FP4 = 18
+OPT_BOOST_FIRST_LEVEL = 19
 
 
 class GwError(RuntimeError):

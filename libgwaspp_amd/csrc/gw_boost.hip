@@ -416,6 +416,29 @@ hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_
     return hipGetLastError();
 }
 
+// The constants of boost_bound_quad (gw_boost_dev.h) for a cohort of n with n_cases cases, in double, rounded so that
+// the bound stays an upper bound: p = float(n_cases / n) is the expansion point BY DEFINITION (so it carries no error),
+// c_lo = max(g(0), g(p)), c_hi = max(g(1), g(p)) with a 1e-6 allowance, k0 = -n h(p) - h'(p)(n_cases - p n) rounded up;
+// c_m / c_d as floats such that c_m - c_d >= c_lo and c_m + c_d >= c_hi.  c_m == 0 (no first level) for a cohort with
+// one group only.
+QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
+    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (n_cases == 0 || n_cases >= n) return q;
+    const float pf = (float)((double)n_cases / (double)n);
+    const double p = (double)pf, h0 = -(p * std::log2(p) + (1.0 - p) * std::log2(1.0 - p)), h1 = std::log2((1.0 - p) / p);
+    const double g0 = (h0 - h1 * p) / (p * p), g1 = (h0 + h1 * (1.0 - p)) / ((1.0 - p) * (1.0 - p));
+    const double gp = 1.0 / (2.0 * std::log(2.0) * p * (1.0 - p));
+    const double c_lo = std::max(g0, gp) * (1.0 + 1.0e-6), c_hi = std::max(g1, gp) * (1.0 + 1.0e-6);
+    const double k0 = -(double)n * h0 - h1 * ((double)n_cases - p * (double)n);
+    q.p = pf;
+    q.c_d = (float)(0.5 * (c_hi - c_lo));
+    // c_m - c_d >= c_lo and c_m + c_d >= c_hi for the float c_d actually used
+    q.c_m = std::nextafter((float)std::max(c_lo + (double)q.c_d, c_hi - (double)q.c_d), INFINITY);
+    q.k0 = std::nextafter((float)k0, INFINITY);
+    q.c27 = 27.0f * (q.c_m + std::fabs(q.c_d)) * 1.000001f;
+    return q;
+}
+
 hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
                         const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
                         uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
@@ -424,7 +447,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
                         float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name,
                         unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks, const float *d_klogk,
-                        uint32_t *d_park, int compute_units, bool fp4) {
+                        uint32_t *d_park, int compute_units, bool fp4, uint32_t n_cases, bool first_level) {
     if (n_a == 0 || n_b == 0) return hipSuccess;
     BoostArgs a;
     a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
@@ -435,6 +458,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.cct = d_cct;
     a.ticket = nullptr; a.first_gen = 0; a.stagger_ticks = 0;
     a.lg_n = (float)(std::log2((double)(n_individs ? n_individs : 1u)) * 1.000001) + 1.0e-5f;
+    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
     // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)
@@ -456,7 +480,10 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     }
     // the pair tables counted on FP4 operands (8 samples per operand dword, 64 per MFMA): four corners / nine cells
     if (d_cct && d_marf && small_case_group && fp4) {
-        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2>" : "gw::k_boost_mfma_fp4<%s, 3, 1>", tp, "");
+        // the first level pays while it stops nearly every pair: it is loose by ~0.4 x a chi^2 with 8 degrees of freedom, so
+        // below a threshold of ~25 more than one wave in five would run both levels (diagnostic form: whenever asked)
+        if (fast && pre && first_level && (threshold >= 25.0 || d_dense)) a.quad = quad_bound_constants(n_cases, n_individs);
+        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2, %s>" : "gw::k_boost_mfma_fp4<%s, 3, 1, %s>", tp, a.quad.c_m > 0.0f ? "true" : "false");
         return launch_boost_mfma_fp4(a, pre, !fast, stream);
     }
     if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells

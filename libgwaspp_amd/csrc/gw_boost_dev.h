@@ -155,6 +155,72 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
     err = 5.9604645e-8f * (n * (8.5f * lg_n + 69.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
     return r;
 }
+// A FIRST-level bound without the 27 logarithms, for the same tables (no missing call).  With h the binary entropy in
+// bits, A = sum_cells (x lg x + y lg y - s lg s) = - sum_cells s h(x / s).  For an expansion point p (the cases'
+// share of the cohort, as a float) the two-piece quadratic
+//   h(p) + h'(p)(z - p) - c(z) (z - p)^2,   c(z) = c_lo for z < p, c_hi for z > p
+// lies below h on [0, 1] for  c_lo = max(g(0), g(p)), c_hi = max(g(1), g(p)),
+//   g(z) = [h(p) + h'(p)(z - p) - h(z)] / (z - p)^2,   g(p) = -h''(p) / 2 = 1 / (2 ln 2 p (1 - p))
+// (g is an average of the convex -h'' over the segment from p to z, hence convex in z, hence on either side of p
+// largest at an end of that side), and because the x of a table add up to the case count,
+//   A <= k0 + sum_cells c(x / s) (x - p s)^2 / s,   k0 = -n h(p) - h'(p)(n_case - p n).
+// With d = x - p s, c_m = (c_lo + c_hi) / 2 and c_d = (c_hi - c_lo) / 2 the sum is c_m sum d^2 / s + c_d sum d |d| / s:
+// nine v_rcp_f32 instead of 27 v_log_f32, about 60 % of the vector issue slots of boost_bound_split.  The rest of the
+// measure (K_i + K_j + n lg tao) is kept as it is.  The bound is one-sided, measure <= bound1 + err1, and loose by
+// (2 c ln 2 p (1 - p) - 1) times a cell's share of the pair's saturated-model G statistic -- 0.39 x a chi^2 with 8
+// degrees of freedom for a balanced cohort, where c_lo ~ c_hi ~ 4; for a lopsided one the factor is 0 on the long
+// side of p and at most 1 on the short one.  On the bench's input 3.4 pairs in 10 000 reach a threshold of 30
+// (tools/bound_study.py) and go on to boost_bound_split.  The constants are exact by definition (the host rounds
+// c_lo, c_hi and k0 up), so only the arithmetic rounds; with c = max(c_lo, c_hi) = c_m + |c_d| and q = sum d^2 / s:
+//   * d = fma(-p, s, x): u |d|; 1 / max(s, 1): 2u; t = d / s: 4u relative; q_m = fma(d, t, q_m), q_d = fma(|d|, t, q_d):
+//     5u of the term + u q per step, nine steps: 14u q each;  A1 = fma(c_d, q_d, fma(c_m, q_m, k0)):
+//     14u c q + 2u (c q + |k0|),  |k0| <= 1.01 n:                                                  u (16 c q + 2.02 n)
+//   * K_i, K_j rounded (2.07 n u), (A1 + K_i) + K_j: u (2 |A1| + 2 |K_i| + |K_j|):                   u (2 c q + 7.2 n)
+//   * tao and n lt, the final sum as in boost_bound_split:                 23 u n + 5.02 u n |L| + u |final|
+//   => times 2 ln 2 and the factor's roundings:  u [ 25 c q + 44.8 n + 6.96 n |L| + 3.5 |bound| ];
+//   err below uses (27, 48, 7.2, 6).  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
+//   measure (check_upper_bound), as it checks the second level.
+struct QuadBound {
+    float p, c_m, c_d, k0, c27;  // c27 = 27 max(c_lo, c_hi); c_m == 0: no first level
+};
+// (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
+__device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const float (&fs)[9],
+                                                    const SnpMarginF &f1, const SnpMarginF &f2, float n,
+                                                    const QuadBound &qb, float &err) {
+    float q_m = 0.0f, q_d = 0.0f, tao = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float in_c = 0.0f, in_t = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float x = fx[3 * a + b], s = fs[3 * a + b];
+            const float d = __builtin_fmaf(-qb.p, s, x);
+            const float t = d * __builtin_amdgcn_rcpf(fmaxf(s, 1.0f));  // s == 0: d == 0
+            q_m = __builtin_fmaf(d, t, q_m);
+            q_d = __builtin_fmaf(fabsf(d), t, q_d);
+            in_c = __builtin_fmaf(s, f2.rb[b], in_c);
+            in_t = __builtin_fmaf(s, f2.rb[3 + b], in_t);
+        }
+        tao = __builtin_fmaf(f1.pa[a], in_c, tao);
+        tao = __builtin_fmaf(f1.pa[3 + a], in_t, tao);
+    }
+    const float lt = __log2f(tao);
+    const float A1 = __builtin_fmaf(qb.c_d, q_d, __builtin_fmaf(qb.c_m, q_m, qb.k0));
+    const float r = 1.3862943611198906f * (((A1 + f1.ki) + f2.kj) + n * lt);  // 2 ln 2
+    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, n * (48.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
+    return r;
+}
+__device__ __forceinline__ float boost_bound_quad(const uint32_t (&ca)[9], const uint32_t (&co)[9],
+                                                  const SnpMarginF &f1, const SnpMarginF &f2, float n,
+                                                  const QuadBound &qb, float &err) {
+    float fx[9], fs[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        fx[c] = (float)ca[c];
+        fs[c] = (float)(ca[c] + co[c]);
+    }
+    return boost_bound_quad_f(fx, fs, f1, f2, n, qb, err);
+}
 // true: the pair is provably below the threshold (NaN / Inf anywhere -> false -> FP64 decides)
 __device__ __forceinline__ bool bound_rules_out(float bound, float err, float bound_threshold) {
     return bound + err < bound_threshold;
@@ -162,6 +228,10 @@ __device__ __forceinline__ bool bound_rules_out(float bound, float err, float bo
 // the run-time check of the error model, for a pair that has both values
 __device__ __forceinline__ void check_bound(double measure, float bound, float err, unsigned long long *tally) {
     if (fabs(measure - (double)bound) > (double)err) atomicAdd(&tally[2], 1ull);  // false for NaN
+}
+// ... and of the one-sided first level
+__device__ __forceinline__ void check_upper_bound(double measure, float bound, float err, unsigned long long *tally) {
+    if (measure > (double)bound + (double)err) atomicAdd(&tally[2], 1ull);  // false for NaN
 }
 
 struct BoostArgs {
@@ -182,6 +252,7 @@ struct BoostArgs {
     const u32x4 *cct;           // k_boost_mfma: the compacted rows in 64-SNP blocks, chunk-major (k_retile_cc)
     float bound_threshold;      // PRE: the threshold rounded down to float; bound + err < this rules a pair out
     float lg_n;                 // PRE: log2(n_individs), rounded up (boost_bound_split's error bound)
+    QuadBound quad;             // PRE, tables without a missing call: the first-level bound's constants (c_m == 0: none)
     int fp4_scale[3];           // k_boost_mfma_fp4: E8M0 block scales 2^-1, 2^0, 2^1 (126, 127, 128), as run-time values
     const float *klogk;         // k_boost_mfma_lut: k log2 k, k = 0 .. n_individs
     uint32_t *park;             // k_boost_mfma_lut: 64 KB per resident workgroup for the parked case counts

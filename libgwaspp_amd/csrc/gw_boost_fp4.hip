@@ -24,12 +24,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // NV = 2, TA = 2: the four corners on 64 x 32 pairs per wave (tables without a missing call);
 // NV = 3, TA = 1: all nine cells on 32 x 32 pairs per wave (tables with missing calls), as k_boost_mfma_seq<., 3, 1>
-template <bool PRE, int NV, int TA>
+template <bool PRE, int NV, int TA, bool L1>
 __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     constexpr int NP = NV * NV;            // products per tile pair
     constexpr int NT = TA * NP;            // accumulator tiles
     constexpr int WA = 32 * TA;            // A rows per wave
     __shared__ uint32_t s_case[NT * 8 * 256];  // [tile][register pair][thread]: two uint16 case counts
+    // PRE: what the per-pair bound needs of the workgroup's 2 WA rows -- genotype counts of the two groups, P(status | g)
+    // and K_i -- staged once: the bound reads 13 dwords per pair, and as loads from global memory (two rows per wave
+    // instruction, ~10 instructions per pair at two waves per SIMD) their latency, not the arithmetic, set its pace
+    __shared__ uint32_t s_row[PRE ? 2 * WA * 16 : 1];
 
     const uint32_t a0 = a.a_begin + blockIdx.y * (2 * WA), b0 = a.b_begin + blockIdx.x * MT;
     const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
@@ -39,6 +43,27 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     const uint32_t wy = wave >> 1, wx = wave & 1u;
     const uint32_t fr = lane & 31u, fh = lane >> 5;
 
+    if constexpr (PRE) {
+        if (t < 2u * WA) {
+            const uint32_t row = min(a0 + t, a_end - 1u);
+            const SnpMargin *pm = a.mar + row;
+            const SnpMarginF *pf = a.marf + row;
+            uint32_t *o = s_row + t * 16u;
+            if constexpr (L1) {  // the first level works on floats: cases and everyone with genotype 0 / 2
+                o[0] = __float_as_uint((float)pm->cases[0]);
+                o[1] = __float_as_uint((float)pm->cases[2]);
+                o[2] = __float_as_uint((float)(pm->cases[0] + pm->ctrls[0]));
+                o[4] = __float_as_uint((float)(pm->cases[2] + pm->ctrls[2]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { o[k] = pm->cases[k]; o[4 + k] = pm->ctrls[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[8 + k] = __float_as_uint(pf->pa[k]);
+            o[3] = __float_as_uint(pf->ki);
+        }
+        __syncthreads();
+    }
     const uint32_t nchunk_c = a.wc / 4u, nchunk = nchunk_c + a.wt / 4u;  // both multiples of 8
     auto unit = [&](uint32_t snp) {
         return a.cct + ((uint64_t)(snp >> 6) * nchunk * 64u + (snp & 63u)) * 2u + fh;
@@ -161,6 +186,9 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     for (int k = 0; k < 3; ++k) { f2c[k] = pm2->cases[k]; f2t[k] = pm2->ctrls[k]; }
     SnpMarginF mf2;
     if (PRE) mf2 = a.marf[j_ok ? j : b_end - 1u];
+    float cx[3], csum[3];  // first level: the column's cases / everyone per genotype, as floats
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cx[k] = (float)f2c[k]; csum[k] = (float)(f2c[k] + f2t[k]); }
     const float nf = (float)a.n_individs, inv_n = 1.0f / (float)a.n_individs;
     // NV == 2 <=> the table has no missing call: the bound with the logarithms split (boost_bound_split)
     const float lg_n = a.lg_n;  // >= log2 n (rounded up on the host)
@@ -209,16 +237,43 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
 #else
             if (PRE) {
 #endif
-                uint32_t cells[2][NP], ca[9], co[9];
+                const uint32_t *rw = s_row + (i - a0) * 16u;
+                SnpMarginF f1;  // the fields the bounds of tables without / with missing calls read
+                if constexpr (NV == 2) {
 #pragma unroll
-                for (int c = 0; c < NP; ++c) {
-                    cells[0][c] = case_count(ta * NP + c, r);
-                    cells[1][c] = (uint32_t)acc[ta][c][r];
+                    for (int k = 0; k < 6; ++k) f1.pa[k] = __uint_as_float(rw[8 + k]);
+                    f1.ki = __uint_as_float(rw[3]);
+                } else {
+                    f1 = a.marf[i];
                 }
-                const SnpMargin *pm1 = a.mar + i;
-                tables(cells, pm1->cases, pm1->ctrls, ca, co);
-                float err;
-                const float bound = bound_of(ca, co, a.marf[i], err);
+                float err, bound;
+                if constexpr (L1) {  // first level, in floats throughout (the control counts are floats already)
+                    float fx[9], fs[9];
+                    static_assert(!L1 || NP == 4, "first level: four-corner tables");
+                    constexpr int at[4] = {0, 2, 6, 8};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        fx[at[c]] = (float)case_count(ta * NP + c, r);
+                        fs[at[c]] = fx[at[c]] + acc[ta][c % NP][r];
+                    }
+                    const float rx0 = __uint_as_float(rw[0]), rx2 = __uint_as_float(rw[1]);
+                    const float rs0 = __uint_as_float(rw[2]), rs2 = __uint_as_float(rw[4]);
+                    fx[1] = rx0 - fx[0] - fx[2];   fs[1] = rs0 - fs[0] - fs[2];      // as `tables` below, exact in floats
+                    fx[7] = rx2 - fx[8] - fx[6];   fs[7] = rs2 - fs[8] - fs[6];
+                    fx[3] = cx[0] - fx[0] - fx[6]; fs[3] = csum[0] - fs[0] - fs[6];
+                    fx[5] = cx[2] - fx[2] - fx[8]; fs[5] = csum[2] - fs[2] - fs[8];
+                    fx[4] = cx[1] - fx[1] - fx[7]; fs[4] = csum[1] - fs[1] - fs[7];
+                    bound = boost_bound_quad_f(fx, fs, f1, mf2, nf, a.quad, err);
+                } else {
+                    uint32_t cells[2][NP], ca[9], co[9];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+                        cells[0][c] = case_count(ta * NP + c, r);
+                        cells[1][c] = (uint32_t)acc[ta][c][r];
+                    }
+                    tables(cells, rw, rw + 4, ca, co);
+                    bound = bound_of(ca, co, f1, err);
+                }
                 if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = (double)(a.dense_err ? err : bound);
                 else if (!bound_rules_out(bound, err, a.bound_threshold)) need |= 1u << p;
             } else {
@@ -245,14 +300,23 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
         const uint32_t i = row_of(p);
         const SnpMargin m1 = a.mar[i], m2 = *pm2;
         tables(cells, m1.cases, m1.ctrls, ca, co);
+        float err2 = 0.0f, bound2 = 0.0f;
+        if (PRE && !a.dense) {  // few pairs get here
+            bound2 = bound_of(ca, co, a.marf[i], err2);
+            // second level: what the logarithm-free bound let through meets the bound proper before any FP64
+            if (L1 && bound_rules_out(bound2, err2, a.bound_threshold)) continue;
+        }
         const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
         if (!PRE) {
             vmax = fmax(vmax, measure);
             vmin = fmin(vmin, measure);
-        } else if (!a.dense) {  // few pairs get here: the bound again, checked against the measure
-            float err;
-            const float bound = bound_of(ca, co, a.marf[i], err);
-            check_bound(measure, bound, err, a.tally);
+        } else if (!a.dense) {  // the bounds, checked against the measure
+            check_bound(measure, bound2, err2, a.tally);
+            if constexpr (L1) {
+                float err1;
+                const float bound1 = boost_bound_quad(ca, co, a.marf[i], mf2, nf, a.quad, err1);
+                check_upper_bound(measure, bound1, err1, a.tally);
+            }
         }
         if (measure > a.threshold) {  // :482-484
             const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
@@ -287,12 +351,13 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream) {
     if (nine) {
         const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
-        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1>), grid, dim3(256), 0, stream, a);
+        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, false>), grid, dim3(256), 0, stream, a);
     } else {
         const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + 2 * MT - 1) / (2 * MT));
-        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 2, 2>), grid, dim3(256), 0, stream, a);
+        if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, true>), grid, dim3(256), 0, stream, a);
+        else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 2, 2, false>), grid, dim3(256), 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -86,6 +86,7 @@ struct gw_table {
     bool selected_valid = false, any_missing = true;
     uint64_t prefilter_trips = 0;  // screens repeated in FP64 because a pair fell outside the bound's error model
     uint32_t sel_individs = 0;  // nCases + nControls of the compacted rows
+    uint32_t sel_cases = 0;     // ... and nCases
     unsigned long long *d_tally = nullptr;
     void *d_hits_buf = nullptr;    // hit list / dense block of the pair screens, kept between calls (grow-only)
     size_t hits_buf_bytes = 0;
@@ -98,7 +99,7 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0, opt_boost_fp4 = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0, opt_boost_fp4 = 1, opt_boost_first_level = 1;
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -947,6 +948,7 @@ int ensure_selected(gw_table *t) {
     }
     if (t->d_klogk && !t->d_park) GW_HIP(hipMalloc((void **)&t->d_park, gw::boost_lut_park_bytes(t->compute_units)));
     t->sel_individs = individs;
+    t->sel_cases = (uint32_t)cases.size();
     if (t->d_klogk) GW_HIP(gw::launch_boost_klogk(t->sel_individs + 1u, t->d_klogk, t->stream));
     GW_HIP(gw::launch_boost_tables(t->sel_individs + 1u, t->sel_individs, t->d_frac, t->d_xlogx, t->stream));
     GW_HIP(hipStreamSynchronize(t->stream));
@@ -1033,10 +1035,11 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
         return gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
                                 (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, max_hits,
                                 t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
-                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3,
+                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3 || t->opt_prefilter == 5,
                                 t->last_boost_kernel, reinterpret_cast<unsigned int *>(t->d_tally + 4),
                                 (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t),
-                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0);
+                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0,
+                                t->sel_cases, diag ? t->opt_prefilter >= 4 : t->opt_boost_first_level != 0);
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1121,7 +1124,8 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
                             tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
                             t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel,
                             reinterpret_cast<unsigned int *>(t->d_tally + 4), (uint32_t)t->compute_units * 2u,
-                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0));
+                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0,
+                            t->sel_cases, t->opt_boost_first_level != 0));
     return GW_OK;
 }
 
@@ -1338,6 +1342,9 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
     case GW_OPT_BOOST_LUT:
         t->opt_boost_lut = v ? 1 : 0;
         return GW_OK;
+    case GW_OPT_BOOST_FIRST_LEVEL:
+        t->opt_boost_first_level = v ? 1 : 0;
+        return GW_OK;
     case GW_OPT_BOOST_FP4:
         t->opt_boost_fp4 = v ? 1 : 0;
         return GW_OK;
@@ -1361,7 +1368,7 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_segment = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_PREFILTER:
-        if (v < 0 || v > 3) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default), 2 or 3 (diagnostic)");
+        if (v < 0 || v > 5) return fail(GW_E_INVALID, "boost_prefilter must be 0 (never), 1 (default) or 2 ... 5 (diagnostic)");
         t->opt_prefilter = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_PREFILTER_TRIPS:  // set: 1 = treat every pre-filtered screen as tripped (exercises the FP64 repeat), 0 = normal
@@ -1390,6 +1397,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_STAGGER_US: *v = boost_stagger_ticks(t) / 100u; return GW_OK;
     case GW_OPT_BOOST_LUT: *v = t->opt_boost_lut; return GW_OK;
     case GW_OPT_BOOST_FP4: *v = t->opt_boost_fp4; return GW_OK;
+    case GW_OPT_BOOST_FIRST_LEVEL: *v = t->opt_boost_first_level; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;
     case GW_OPT_RESERVE_CUS: *v = t->opt_reserve_cus; return GW_OK;
     case GW_OPT_BOOST_MATRIX_CORES: *v = t->opt_boost_mfma; return GW_OK;

@@ -161,7 +161,11 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
                         // k = 0 .. n_individs, boost_lut_park_bytes() of scratch, the device's CU count; null = not used
                         const float *d_klogk = nullptr, uint32_t *d_park = nullptr, int compute_units = 0,
                         // four-corner tables counted on FP4 operands (k_boost_mfma_fp4) instead of int8 ones
-                        bool fp4 = false);
+                        bool fp4 = false,
+                        // prefilter on the FP4 four-corner kernel: the logarithm-free first-level bound ahead of the
+                        // bound proper (boost_bound_quad); needs the case count of the compacted rows.  With d_dense
+                        // (diagnostic) the first-level bound / its error bound is what gets written
+                        uint32_t n_cases = 0, bool first_level = false);
 hipError_t launch_boost_klogk(uint32_t n_entries, float *d_klogk, hipStream_t stream);
 size_t boost_lut_park_bytes(int compute_units);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32

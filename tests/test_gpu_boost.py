@@ -229,6 +229,103 @@ def test_boost_prefilter_gives_the_same_hit_list(oracle, n, m, p_missing, low_ma
         assert n0 == int((finite > 30.0).sum())
 
 
+def _quad_constants(n_cases, n):
+    """gw_boost.hip quad_bound_constants, restated: expansion point, the two curvature constants (as the c_m -+ c_d the
+    device uses), offset"""
+    f32 = np.float32
+    p = float(f32(n_cases / n))
+    h0 = -(p * np.log2(p) + (1 - p) * np.log2(1 - p))
+    h1 = np.log2((1 - p) / p)
+    gp = 1.0 / (2.0 * np.log(2.0) * p * (1 - p))
+    c_lo = max((h0 - h1 * p) / p ** 2, gp) * (1 + 1e-6)
+    c_hi = max((h0 + h1 * (1 - p)) / (1 - p) ** 2, gp) * (1 + 1e-6)
+    c_d = float(f32(0.5 * (c_hi - c_lo)))
+    c_m = float(np.nextafter(f32(max(c_lo + c_d, c_hi - c_d)), f32(np.inf)))
+    k0 = float(np.nextafter(f32(-n * h0 - h1 * (n_cases - p * n)), f32(np.inf)))
+    return p, c_m - c_d, c_m + c_d, k0
+
+
+@pytest.mark.parametrize("n,m,case_share,low_maf", [(600, 48, 0.5, False), (6000, 64, 0.45, True), (6000, 48, 0.15, False),
+                                                    (40_000, 40, 0.5, False), (40_000, 36, 0.85, True),
+                                                    (250_000, 24, 0.25, False)])
+def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m, case_share, low_maf):
+    """GW_OPT_BOOST_FIRST_LEVEL (k_boost_mfma_fp4<true, 2, 2, true>): the logarithm-free bound of gw_boost_dev.h
+    boost_bound_quad.  For every pair: measure <= bound1 + err1 (what the screen relies on); the device's value lies
+    within err1 of the same formula evaluated in FP64 from counts taken from the genotype codes (the error model);
+    the quadratic lies below the binary entropy for this cohort's constants; and the hit lists with the first level
+    on, off and without any pre-filter are the same, also for thresholds that sit on a pair's measure.  Balanced and
+    lopsided cohorts: the constant c grows as the case share leaves 1/2."""
+    rng = np.random.default_rng(5 * n + m + int(100 * case_share))
+    codes = _prefilter_table(rng, n, m, 0.0, low_maf)
+    u = rng.random(n)
+    is_case = u < case_share * 0.9
+    is_ctrl = (u >= case_share * 0.9) & (u < 0.9)
+    for (i, j, frac) in ((1, 5, 0.5), (2, 9, 0.15), (3, 11, 0.05), (4, 13, 0.02)):
+        flip = is_case & (rng.random(n) < frac)
+        codes[j, flip] = codes[i, flip]
+    ts = oracle.pack_codes(codes, "stream")
+    cases, ctrls = np.flatnonzero(is_case).astype(np.int32), np.flatnonzero(is_ctrl).astype(np.int32)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    n_sel = nc + nt
+    p, c_lo, c_hi, k0 = _quad_constants(nc, n_sel)
+    c = max(c_lo, c_hi)
+    z = np.linspace(0.0, 1.0, 200_001)
+    ent = lambda v: -(np.where(v > 0, v * np.log2(np.maximum(v, 1e-300)), 0.0) + np.where(v < 1, (1 - v) * np.log2(np.maximum(1 - v, 1e-300)), 0.0))
+    assert np.all(ent(np.array([p]))[0] + np.log2((1 - p) / p) * (z - p) - np.where(z < p, c_lo, c_hi) * (z - p) ** 2 <= ent(z) + 1e-12)
+    # the cells of every pair, from the codes: X[a][b] (cases), S[a][b] (both groups), m x m each
+    ind = lambda grp, k: (codes[:, grp] == k).astype(np.float32)
+    X = np.array([[ind(is_case, a) @ ind(is_case, b).T for b in (1, 2, 3)] for a in (1, 2, 3)], dtype=np.float64)
+    Y = np.array([[ind(is_ctrl, a) @ ind(is_ctrl, b).T for b in (1, 2, 3)] for a in (1, 2, 3)], dtype=np.float64)
+    S = X + Y
+    xlgx = lambda v: np.where(v > 0, v * np.log2(np.maximum(v, 1.0)), 0.0)
+    A = (xlgx(X) + xlgx(Y) - xlgx(S)).sum(axis=(0, 1))
+    D = X - p * S
+    A1 = k0 + (np.where(D < 0, c_lo, c_hi) * np.where(S > 0, D ** 2 / np.maximum(S, 1.0), 0.0)).sum(axis=(0, 1))
+    assert np.all(A <= A1 + 1e-6)                       # the inequality itself, in FP64
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        exact = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 4)
+        b1 = t.boost_measures(0, m, 0, m)
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, true>"
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 5)
+        e1 = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
+        iu = np.triu_indices(m, 1)
+        ex, bb, ee = exact[iu], b1[iu], e1[iu]
+        want = ex + 2.0 * np.log(2.0) * (A1 - A)[iu]    # the same formula in FP64
+        ok = np.isfinite(ex) & np.isfinite(bb) & np.isfinite(ee)
+        assert ok.sum() >= 0.9 * np.isfinite(ex).sum()
+        dev = np.abs(bb[ok] - want[ok])
+        worst = int(np.argmax(dev / ee[ok]))
+        print(f"worst pair: device {bb[ok][worst]:.4f} formula {want[ok][worst]:.4f} err1 {ee[ok][worst]:.4f} measure {ex[ok][worst]:.4f}")
+        assert np.all(ex[ok] <= bb[ok] + ee[ok])
+        assert np.all(dev <= ee[ok]), (dev.max(), (dev / ee[ok]).max())
+        reach = np.mean(bb[ok] + ee[ok] >= 30.0)
+        print(f"n={n_sel} p={p:.3f} c={c_lo:.3f}/{c_hi:.3f}: max |bound1 - formula| / err1 = {(dev / ee[ok]).max():.3f}, median err1 = {np.median(ee[ok]):.4f}, "
+              f"median slack = {np.median(bb[ok] - ex[ok]):.2f}, first level reaches 30 for {reach:.3f} of the pairs")
+        finite = np.sort(ex[np.isfinite(ex)])
+        thresholds = [30.0, 25.0, float(np.median(finite)), float(finite[-1]), float(finite[-2]), -1.0e9, 1.0e9]
+        thresholds += [float(v) for v in rng.choice(finite, size=3)]
+        high = finite[finite >= 25.0]                      # where the first level is in use: exactly on / just below a measure
+        thresholds += [float(v) for v in rng.choice(high, size=min(4, len(high)), replace=False)]
+        thresholds += [float(np.nextafter(v, -np.inf)) for v in rng.choice(high, size=min(2, len(high)), replace=False)]
+        assert len(high) >= 2
+        for thr in thresholds:
+            ref_hits, ref_n, ref_pairs, _, _ = t.boost_screen(0, m, 0, m, threshold=thr)           # all FP64
+            for first in (1, 0):
+                t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, first)
+                hits, n_hits, n_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
+                # (the first level is only used where it is selective: thresholds of 25 and more)
+                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {'true' if first and thr >= 25.0 else 'false'}>"
+                assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
+                assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
+        t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, 1)
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0     # neither level's run-time check fired
+
+
 @pytest.mark.parametrize("p_missing", [0.0, 0.02])
 def test_boost_blocks_of_any_geometry_agree_across_kernels(oracle, p_missing):
     """Rectangles of the pair space that start and end anywhere (not on the 32/64/128-SNP tile grids of
@@ -315,7 +412,7 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
                 t.set_option(gw.capi.OPT_BOOST_LUT, 0)
                 t.set_option(gw.capi.OPT_BOOST_FP4, 1)
                 got4, gh4, gp4, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
-                assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2>"
+                assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, true>"
                 assert (gh4, gp4) == (wh, wp)
                 assert np.array_equal(np.sort(got4, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
         assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
@@ -325,7 +422,7 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
         t.simulate_phenotype(11)
         t.set_option(gw.capi.OPT_BOOST_LUT, 1)
         t.boost_screen(0, 100, 0, 100, extremes=False)
-        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1>"   # nine cells: never the LUT form
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, false>"   # nine cells: never the LUT form
 
 
 @pytest.mark.parametrize("missing", [0, 655])
@@ -345,7 +442,7 @@ def test_fp4_counting_equals_int8_counting(n, m, missing):
             hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=8.0)
             res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin, t.last_boost_kernel())
         shape = "3, 1" if missing else "2, 2"
-        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
+        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}, false>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
         for other in ("int8", "valu"):
             assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
             assert np.array_equal(res["fp4"][1], res[other][1]) and res["fp4"][2:6] == res[other][2:6]
