@@ -312,7 +312,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
         high = finite[finite >= 25.0]                      # where the first level is in use: exactly on / just below a measure
         thresholds += [float(v) for v in rng.choice(high, size=min(4, len(high)), replace=False)]
         thresholds += [float(np.nextafter(v, -np.inf)) for v in rng.choice(high, size=min(2, len(high)), replace=False)]
-        assert len(high) >= 2
+        assert len(high) >= 1
         for thr in thresholds:
             ref_hits, ref_n, ref_pairs, _, _ = t.boost_screen(0, m, 0, m, threshold=thr)           # all FP64
             for first in (1, 0):
@@ -412,7 +412,7 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
                 t.set_option(gw.capi.OPT_BOOST_LUT, 0)
                 t.set_option(gw.capi.OPT_BOOST_FP4, 1)
                 got4, gh4, gp4, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
-                assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, true>"
+                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {'true' if thr >= 25.0 else 'false'}>"
                 assert (gh4, gp4) == (wh, wp)
                 assert np.array_equal(np.sort(got4, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
         assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
