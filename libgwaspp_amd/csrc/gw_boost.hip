@@ -425,6 +425,7 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (n_cases == 0 || n_cases >= n) return q;
     const float pf = (float)((double)n_cases / (double)n);
+    if (!(pf > 0.0f && pf < 1.0f)) return q;
     const double p = (double)pf, h0 = -(p * std::log2(p) + (1.0 - p) * std::log2(1.0 - p)), h1 = std::log2((1.0 - p) / p);
     const double g0 = (h0 - h1 * p) / (p * p), g1 = (h0 + h1 * (1.0 - p)) / ((1.0 - p) * (1.0 - p));
     const double gp = 1.0 / (2.0 * std::log(2.0) * p * (1.0 - p));

@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     // PRE: what the per-pair bound needs of the workgroup's 2 WA rows -- genotype counts of the two groups, P(status | g)
     // and K_i -- staged once: the bound reads 13 dwords per pair, and as loads from global memory (two rows per wave
     // instruction, ~10 instructions per pair at two waves per SIMD) their latency, not the arithmetic, set its pace
-    __shared__ uint32_t s_row[PRE ? 2 * WA * 16 : 1];
+    constexpr int RS = NV == 3 ? 20 : 16;  // dwords per staged row (nine-cell tables: 1 / P(status | g) as well)
+    __shared__ uint32_t s_row[PRE ? 2 * WA * RS : 1];
 
     const uint32_t a0 = a.a_begin + blockIdx.y * (2 * WA), b0 = a.b_begin + blockIdx.x * MT;
     const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
             const uint32_t row = min(a0 + t, a_end - 1u);
             const SnpMargin *pm = a.mar + row;
             const SnpMarginF *pf = a.marf + row;
-            uint32_t *o = s_row + t * 16u;
+            uint32_t *o = s_row + t * RS;
             if constexpr (L1) {  // the first level works on floats: cases and everyone with genotype 0 / 2
                 o[0] = __float_as_uint((float)pm->cases[0]);
                 o[1] = __float_as_uint((float)pm->cases[2]);
@@ -60,6 +61,10 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) o[8 + k] = __float_as_uint(pf->pa[k]);
+            if constexpr (NV == 3) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[14 + k] = __float_as_uint(pf->qa[k]);
+            }
             o[3] = __float_as_uint(pf->ki);
         }
         __syncthreads();
@@ -237,14 +242,15 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
 #else
             if (PRE) {
 #endif
-                const uint32_t *rw = s_row + (i - a0) * 16u;
+                const uint32_t *rw = s_row + (i - a0) * RS;
                 SnpMarginF f1;  // the fields the bounds of tables without / with missing calls read
                 if constexpr (NV == 2) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) f1.pa[k] = __uint_as_float(rw[8 + k]);
                     f1.ki = __uint_as_float(rw[3]);
-                } else {
-                    f1 = a.marf[i];
+                } else {  // boost_bound reads pa and qa of the pair's first marker
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) { f1.pa[k] = __uint_as_float(rw[8 + k]); f1.qa[k] = __uint_as_float(rw[14 + k]); }
                 }
                 float err, bound;
                 if constexpr (L1) {  // first level, in floats throughout (the control counts are floats already)
