@@ -88,8 +88,8 @@ public:
     // scan window k+1 on a worker thread while the caller walks window k (on by default)
     void setPrefetch(bool on) { drop_prefetch(); prefetch = on; }
     // the reference's CaseControlSet has no change counter, so a set edited in place is recognised from its mask
-    // bytes: all of them at selectCaseControl() and at every new window of rows, object + counts + 32 sampled
-    // words per mask on the calls in between (the reference's loops never edit a set mid-walk).  true = compare
+    // bytes: all of them at selectCaseControl() and at every new window of rows; on the calls in between object +
+    // counts, and 32 sampled words per mask on every 16th (the reference's loops never edit a set mid-walk).  true = compare
     // all bytes on every getter call (N/4 bytes of host reads per call)
     void setMaskCheckEveryCall(bool on) { check_every_call = on; }
     gw_table *handle() { settle(); return tbl; }
@@ -142,6 +142,7 @@ protected:
     std::vector<ushort> installed_case_mask, installed_ctrl_mask;   // what the device holds (stream packing)
     uint64_t installed_sample[2];
     bool check_every_call;
+    uint calls_since_sample;
 
     // pair getters: the reference's loops walk (i, j), (i, j+1), ... -- a run of pairs of the same first marker
     // is fetched in one launch (the run grows x4 while the walk stays sequential, 1 .. 4096 pairs)
