@@ -132,3 +132,46 @@ def test_boost_measure_equals_pairwise_llr(oracle, name, cs, ct, llr):
     m2 = oracle.marginal_information(tuple(int(v) for v in cs.sum(axis=0)) + (0,),
                                      tuple(int(v) for v in ct.sum(axis=0)) + (0,), n)
     assert oracle.boost_measure(case16, ctrl16, m1, m2, n) == pytest.approx(llr, rel=1e-10)
+
+
+def test_boost_measure_equals_its_information_identity(oracle):
+    """An independent derivation of computeBoost's measure (epistasis_func.cpp:424-470) for tables without a missing
+    call, in numpy from the genotype codes: with lg = log2, x / y the case / control count of a cell and s = x + y,
+        measure = 2 ln 2 [ sum_cells (x lg x + y lg y - s lg s) + n H(status | SNP i) + n H(status | SNP j)
+                           - n H(status) + n lg tao ],
+        tao = sum_{a, b, c} p(a, b) p(a, c) p(b, c) / (p(a) p(b) p(c))          (c = status),
+    i.e. n times [H(C|A) + H(C|B) - H(C|A,B) - H(C)] in bits plus the Kirkwood normaliser -- the identity the device's
+    single-precision bounds are built on (gw_boost_dev.h boost_bound_split / boost_bound_quad).  All pairs of 160
+    simulated SNPs (exact-count rows, affy6 spectrum) x 3000 samples against the oracle's restatement of the reference
+    loop.  Parity unpinned like the measure itself: two derivations agreeing, not a reference-held output."""
+    n, m, seed = 3000, 160, 0xB005
+    table, g = oracle.sim_table_stream(seed, 0, m, n, 0, exact=True)
+    cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+    nb = g.data_blocks
+    bits = lambda blocks: np.unpackbits(np.ascontiguousarray(blocks).astype("<u2").view(np.uint8), bitorder="little").reshape(blocks.shape[0], -1)[:, :n]
+    codes = bits(table[:, 1:1 + nb]) + 2 * bits(table[:, 1 + nb:1 + 2 * nb])
+    case, ctrl = bits(cs[None, :])[0].astype(bool), bits(ct[None, :])[0].astype(bool)
+    assert case.sum() == nc and ctrl.sum() == nt and not np.any(codes == 0)
+    ind = lambda grp, k: (codes[:, grp] == k).astype(np.float64)
+    X = np.array([[ind(case, a) @ ind(case, b).T for b in (1, 2, 3)] for a in (1, 2, 3)])
+    Y = np.array([[ind(ctrl, a) @ ind(ctrl, b).T for b in (1, 2, 3)] for a in (1, 2, 3)])
+    S, nn = X + Y, float(nc + nt)
+    xlgx = lambda v: np.where(v > 0, v * np.log2(np.maximum(v, 1.0)), 0.0)
+    A = (xlgx(X) + xlgx(Y) - xlgx(S)).sum(axis=(0, 1))                      # -n H(C | A, B)
+    cond = lambda mx, my: -(xlgx(mx) + xlgx(my) - xlgx(mx + my)).sum(axis=0)   # n H(C | one SNP)
+    Ki, Kj = cond(X.sum(axis=1), Y.sum(axis=1)), cond(X.sum(axis=0), Y.sum(axis=0))
+    hC = -(nc * np.log2(nc / nn) + nt * np.log2(nt / nn))                  # n H(C)
+    pab = S / nn
+    pa, pb = pab.sum(axis=1), pab.sum(axis=0)
+    tao = np.zeros_like(A)
+    for cnts, tot in ((X, nc), (Y, nt)):
+        pac, pbc = cnts.sum(axis=1) / nn, cnts.sum(axis=0) / nn
+        for a in range(3):
+            for b in range(3):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tao += np.nan_to_num(pab[a, b] * pac[a] * pbc[b] / (pa[a] * pb[b] * (tot / nn)))
+    mine = 2.0 * np.log(2.0) * (A + Ki + Kj - hC + nn * np.log2(tao))[np.triu_indices(m, 1)]
+    ref = oracle.boost_all_pairs(table, g, cs, ct, nc, nt)
+    ok = np.isfinite(ref) & np.isfinite(mine)
+    assert ok.sum() > 0.9 * ref.size
+    assert np.max(np.abs(mine[ok] - ref[ok])) < 1e-8
