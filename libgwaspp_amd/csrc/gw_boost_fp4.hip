@@ -116,26 +116,37 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     auto expand = [](const uint32_t (&w)[4], int k) -> i32x8 {
         i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = k < 3 ? (int)(w[j] & (0x11111111u << k)) : (int)((w[j] >> 3) & 0x11111111u);
+        for (int j = 0; j < 4; ++j) v[j] = (int)(w[j] & (0x11111111u << (k < 3 ? k : 0)));  // k = 3: words already shifted down
         return v;
     };
+    // k = 3 (the sign bit): the PLANES are shifted down once (two shifts per word) and the class is taken of the shifted
+    // planes, so that class and mask fuse into one v_bitop3_b32 as they do for k < 3 -- shifting every class word
+    // instead cost three instructions per operand dword where this costs two (24 of 144 per 32 MFMAs)
+    auto down3 = [](const u32x4 &v) -> u32x4 { return u32x4{v[0] >> 3, v[1] >> 3, v[2] >> 3, v[3] >> 3}; };
     auto chunk_pair = [&](const u32x4 (&va0)[TA], const u32x4 (&va1)[TA], const u32x4 &vb0, const u32x4 &vb1) {
-        uint32_t ca[TA][NV][4], cb[NV][4];
-#pragma unroll
-        for (int c = 0; c < NV; ++c)
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-#pragma unroll
-                for (int ta = 0; ta < TA; ++ta) {
-                    ca[ta][c][w] = cls(va0[ta], c, w);
-                    ca[ta][c][2 + w] = cls(va1[ta], c, w);
-                }
-                cb[c][w] = cls(vb0, c, w);
-                cb[c][2 + w] = cls(vb1, c, w);
-            }
         static_for<0, 4>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const int sc = k == 1 ? sc_one : (k == 2 ? sc_half : sc_two);  // values 1 / 2 / 0.5 (k = 0, 3) -> products of 1
+            uint32_t ca[TA][NV][4], cb[NV][4];
+            u32x4 wa0[TA], wa1[TA];
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) {
+                wa0[ta] = k == 3 ? down3(va0[ta]) : va0[ta];
+                wa1[ta] = k == 3 ? down3(va1[ta]) : va1[ta];
+            }
+            const u32x4 wb0 = k == 3 ? down3(vb0) : vb0, wb1 = k == 3 ? down3(vb1) : vb1;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int ta = 0; ta < TA; ++ta) {
+                        ca[ta][c][w] = cls(wa0[ta], c, w);
+                        ca[ta][c][2 + w] = cls(wa1[ta], c, w);
+                    }
+                    cb[c][w] = cls(wb0, c, w);
+                    cb[c][2 + w] = cls(wb1, c, w);
+                }
             i32x8 xa[TA][NV], yb[NV];
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
