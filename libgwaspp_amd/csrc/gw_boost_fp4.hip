@@ -180,6 +180,13 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
                 for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
                 ub[k + d] = gb[nxt];
             }
+#ifndef GW_FP4_LOADS_AT_END
+            // The refill belongs HERE in the instruction stream, right behind the MFMA group that used the registers: left
+            // alone, the scheduler sinks all of a round's loads below its last MFMA (the groups above only name MFMA and
+            // VALU), and the first half of the next round then waits for loads issued a few instructions earlier
+            // (measured in alternating processes on one box: 72.5 - 72.9 ms with the loads at the end, 71.4 - 71.5 so)
+            __builtin_amdgcn_sched_barrier(0);  // nothing moves across: the loads stay between the two MFMA groups
+#endif
         });
     };
     for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
