@@ -432,6 +432,13 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     const double c_lo = std::max(g0, gp) * (1.0 + 1.0e-6), c_hi = std::max(g1, gp) * (1.0 + 1.0e-6);
     const double k0 = -(double)n * h0 - h1 * ((double)n_cases - p * (double)n);
     q.p = pf;
+    if (std::fabs(c_hi - c_lo) <= 0.02 * std::max(c_hi, c_lo)) {  // balanced cohort: one constant, the larger (LV = 1)
+        q.c_d = 0.0f;
+        q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
+        q.k0 = std::nextafter((float)k0, INFINITY);
+        q.c27 = 27.0f * q.c_m * 1.000001f;
+        return q;
+    }
     q.c_d = (float)(0.5 * (c_hi - c_lo));
     // c_m - c_d >= c_lo and c_m + c_d >= c_hi for the float c_d actually used
     q.c_m = std::nextafter((float)std::max(c_lo + (double)q.c_d, c_hi - (double)q.c_d), INFINITY);
@@ -484,7 +491,8 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
         // the first level pays while it stops nearly every pair: it is loose by ~0.4 x a chi^2 with 8 degrees of freedom, so
         // below a threshold of ~25 more than one wave in five would run both levels (diagnostic form: whenever asked)
         if (fast && pre && first_level && (threshold >= 25.0 || d_dense)) a.quad = quad_bound_constants(n_cases, n_individs);
-        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2, %s>" : "gw::k_boost_mfma_fp4<%s, 3, 1, %s>", tp, a.quad.c_m > 0.0f ? "true" : "false");
+        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2, %s>" : "gw::k_boost_mfma_fp4<%s, 3, 1, %s>", tp,
+             a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
         return launch_boost_mfma_fp4(a, pre, !fast, stream);
     }
     if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells

@@ -184,6 +184,9 @@ struct QuadBound {
     float p, c_m, c_d, k0, c27;  // c27 = 27 max(c_lo, c_hi); c_m == 0: no first level
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
+// TWO = false: one curvature constant for both sides (the host sets c_m = max(c_lo, c_hi), c_d = 0 -- what a balanced
+// cohort gets, where the two differ by a percent): the nine multiply-adds of q_d are not issued.
+template <bool TWO = true>
 __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const float (&fs)[9],
                                                     const SnpMarginF &f1, const SnpMarginF &f2, float n,
                                                     const QuadBound &qb, float &err) {
@@ -197,7 +200,7 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
             const float d = __builtin_fmaf(-qb.p, s, x);
             const float t = d * __builtin_amdgcn_rcpf(fmaxf(s, 1.0f));  // s == 0: d == 0
             q_m = __builtin_fmaf(d, t, q_m);
-            q_d = __builtin_fmaf(fabsf(d), t, q_d);
+            if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
             in_c = __builtin_fmaf(s, f2.rb[b], in_c);
             in_t = __builtin_fmaf(s, f2.rb[3 + b], in_t);
         }
@@ -205,7 +208,8 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
         tao = __builtin_fmaf(f1.pa[3 + a], in_t, tao);
     }
     const float lt = __log2f(tao);
-    const float A1 = __builtin_fmaf(qb.c_d, q_d, __builtin_fmaf(qb.c_m, q_m, qb.k0));
+    const float A0 = __builtin_fmaf(qb.c_m, q_m, qb.k0);
+    const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
     const float r = 1.3862943611198906f * (((A1 + f1.ki) + f2.kj) + n * lt);  // 2 ln 2
     err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, n * (48.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
     return r;

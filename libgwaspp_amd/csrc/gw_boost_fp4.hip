@@ -24,8 +24,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // NV = 2, TA = 2: the four corners on 64 x 32 pairs per wave (tables without a missing call);
 // NV = 3, TA = 1: all nine cells on 32 x 32 pairs per wave (tables with missing calls), as k_boost_mfma_seq<., 3, 1>
-template <bool PRE, int NV, int TA, bool L1>
+// LV: the first-level bound -- 0 none, 1 one curvature constant (balanced cohorts), 2 two-piece quadratic
+template <bool PRE, int NV, int TA, int LV>
 __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
+    constexpr bool L1 = LV != 0;
     constexpr int NP = NV * NV;            // products per tile pair
     constexpr int NT = TA * NP;            // accumulator tiles
     constexpr int WA = 32 * TA;            // A rows per wave
@@ -247,14 +249,14 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     };
 
     uint32_t need = 0;
-    unsigned long long n_eval = 0;
+    uint32_t n_valid = 0;  // at most 32 per lane
     // (the bound for two pairs at a time with packed FP32 multiply-adds -- 213 instead of 253 instructions per pair -- was
     // measured slower, 84.5 vs 82.8 ms in alternating processes on one box: profiles/r03_c5_experiments.txt)
     static_for<0, 16 * TA>([&](auto pc) {
         constexpr int p = decltype(pc)::value, ta = p >> 4, r = p & 15;
         const uint32_t i = row_of(p);
         if (i < a_end && j_ok && i < j) {
-            ++n_eval;
+            ++n_valid;
 #ifdef GW_FP4_NO_BOUND   // measurement only (tools/build_variant_file.sh): the launch without any per-pair work
             if (a.n_individs < 0) {
 #else
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
                     fx[3] = cx[0] - fx[0] - fx[6]; fs[3] = csum[0] - fs[0] - fs[6];
                     fx[5] = cx[2] - fx[2] - fx[8]; fs[5] = csum[2] - fs[2] - fs[8];
                     fx[4] = cx[1] - fx[1] - fx[7]; fs[4] = csum[1] - fs[1] - fs[7];
-                    bound = boost_bound_quad_f(fx, fs, f1, mf2, nf, a.quad, err);
+                    bound = boost_bound_quad_f<LV == 2>(fx, fs, f1, mf2, nf, a.quad, err);
                 } else {
                     uint32_t cells[2][NP], ca[9], co[9];
 #pragma unroll
@@ -308,6 +310,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
         }
     });
 
+    unsigned long long n_eval = n_valid;
     double vmax = -1.0e300, vmin = 1.0e300;
     while (need) {
         const int p = __ffs((int)need) - 1;
@@ -375,13 +378,14 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream) {
     if (nine) {
         const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
-        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, false>), grid, dim3(256), 0, stream, a);
+        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, 0>), grid, dim3(256), 0, stream, a);
     } else {
         const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + 2 * MT - 1) / (2 * MT));
-        if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, true>), grid, dim3(256), 0, stream, a);
-        else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 2, 2, false>), grid, dim3(256), 0, stream, a);
+        if (pre && a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 2>), grid, dim3(256), 0, stream, a);
+        else if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 1>), grid, dim3(256), 0, stream, a);
+        else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 0>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 2, 2, 0>), grid, dim3(256), 0, stream, a);
     }
     return hipGetLastError();
 }

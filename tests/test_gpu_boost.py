@@ -239,22 +239,25 @@ def _quad_constants(n_cases, n):
     gp = 1.0 / (2.0 * np.log(2.0) * p * (1 - p))
     c_lo = max((h0 - h1 * p) / p ** 2, gp) * (1 + 1e-6)
     c_hi = max((h0 + h1 * (1 - p)) / (1 - p) ** 2, gp) * (1 + 1e-6)
+    k0 = float(np.nextafter(f32(-n * h0 - h1 * (n_cases - p * n)), f32(np.inf)))
+    if abs(c_hi - c_lo) <= 0.02 * max(c_hi, c_lo):     # balanced cohort: one constant for both sides (LV = 1)
+        c = float(np.nextafter(f32(max(c_lo, c_hi)), f32(np.inf)))
+        return p, c, c, k0, 1
     c_d = float(f32(0.5 * (c_hi - c_lo)))
     c_m = float(np.nextafter(f32(max(c_lo + c_d, c_hi - c_d)), f32(np.inf)))
-    k0 = float(np.nextafter(f32(-n * h0 - h1 * (n_cases - p * n)), f32(np.inf)))
-    return p, c_m - c_d, c_m + c_d, k0
+    return p, c_m - c_d, c_m + c_d, k0, 2
 
 
 @pytest.mark.parametrize("n,m,case_share,low_maf", [(600, 48, 0.5, False), (6000, 64, 0.45, True), (6000, 48, 0.15, False),
                                                     (40_000, 40, 0.5, False), (40_000, 36, 0.85, True),
                                                     (250_000, 24, 0.25, False)])
 def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m, case_share, low_maf):
-    """GW_OPT_BOOST_FIRST_LEVEL (k_boost_mfma_fp4<true, 2, 2, true>): the logarithm-free bound of gw_boost_dev.h
+    """GW_OPT_BOOST_FIRST_LEVEL (k_boost_mfma_fp4<true, 2, 2, 1 or 2>): the logarithm-free bound of gw_boost_dev.h
     boost_bound_quad.  For every pair: measure <= bound1 + err1 (what the screen relies on); the device's value lies
     within err1 of the same formula evaluated in FP64 from counts taken from the genotype codes (the error model);
     the quadratic lies below the binary entropy for this cohort's constants; and the hit lists with the first level
     on, off and without any pre-filter are the same, also for thresholds that sit on a pair's measure.  Balanced and
-    lopsided cohorts: the constant c grows as the case share leaves 1/2."""
+    lopsided cohorts (one curvature constant where the two sides differ by under 2 %, the two-piece form elsewhere)."""
     rng = np.random.default_rng(5 * n + m + int(100 * case_share))
     codes = _prefilter_table(rng, n, m, 0.0, low_maf)
     u = rng.random(n)
@@ -268,7 +271,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
     _, cs, nc = oracle.ccs_masks(cases, n)
     _, ct, nt = oracle.ccs_masks(ctrls, n)
     n_sel = nc + nt
-    p, c_lo, c_hi, k0 = _quad_constants(nc, n_sel)
+    p, c_lo, c_hi, k0, level = _quad_constants(nc, n_sel)
     c = max(c_lo, c_hi)
     z = np.linspace(0.0, 1.0, 200_001)
     ent = lambda v: -(np.where(v > 0, v * np.log2(np.maximum(v, 1e-300)), 0.0) + np.where(v < 1, (1 - v) * np.log2(np.maximum(1 - v, 1e-300)), 0.0))
@@ -289,7 +292,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
         exact = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 4)
         b1 = t.boost_measures(0, m, 0, m)
-        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, true>"
+        assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {level}>"
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 5)
         e1 = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
@@ -319,7 +322,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
                 t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, first)
                 hits, n_hits, n_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
                 # (the first level is only used where it is selective: thresholds of 25 and more)
-                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {'true' if first and thr >= 25.0 else 'false'}>"
+                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {level if first and thr >= 25.0 else 0}>"
                 assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
                 assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
         t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, 1)
@@ -412,7 +415,9 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
                 t.set_option(gw.capi.OPT_BOOST_LUT, 0)
                 t.set_option(gw.capi.OPT_BOOST_FP4, 1)
                 got4, gh4, gp4, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
-                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {'true' if thr >= 25.0 else 'false'}>"
+                # (first level from a threshold of 25: one curvature constant or the two-piece form, by the cohort's balance)
+                assert t.last_boost_kernel() in ([f"gw::k_boost_mfma_fp4<true, 2, 2, {v}>" for v in (1, 2)] if thr >= 25.0 else
+                                                 ["gw::k_boost_mfma_fp4<true, 2, 2, 0>"])
                 assert (gh4, gp4) == (wh, wp)
                 assert np.array_equal(np.sort(got4, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
         assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
@@ -422,7 +427,7 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
         t.simulate_phenotype(11)
         t.set_option(gw.capi.OPT_BOOST_LUT, 1)
         t.boost_screen(0, 100, 0, 100, extremes=False)
-        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, false>"   # nine cells: never the LUT form
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0>"   # nine cells: never the LUT form
 
 
 @pytest.mark.parametrize("missing", [0, 655])
@@ -442,7 +447,7 @@ def test_fp4_counting_equals_int8_counting(n, m, missing):
             hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=8.0)
             res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin, t.last_boost_kernel())
         shape = "3, 1" if missing else "2, 2"
-        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}, false>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
+        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}, 0>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
         for other in ("int8", "valu"):
             assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
             assert np.array_equal(res["fp4"][1], res[other][1]) and res["fp4"][2:6] == res[other][2:6]
