@@ -422,7 +422,7 @@ hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_
 // c_m / c_d as floats such that c_m - c_d >= c_lo and c_m + c_d >= c_hi.  c_m == 0 (no first level) for a cohort with
 // one group only.
 QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
-    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (n_cases == 0 || n_cases >= n) return q;
     const float pf = (float)((double)n_cases / (double)n);
     if (!(pf > 0.0f && pf < 1.0f)) return q;
@@ -432,6 +432,8 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     const double c_lo = std::max(g0, gp) * (1.0 + 1.0e-6), c_hi = std::max(g1, gp) * (1.0 + 1.0e-6);
     const double k0 = -(double)n * h0 - h1 * ((double)n_cases - p * (double)n);
     q.p = pf;
+    q.n48 = std::nextafter(48.0f * (float)n, INFINITY);
+    q.n72 = std::nextafter(7.2f * (float)n, INFINITY);
     if (std::fabs(c_hi - c_lo) <= 0.02 * std::max(c_hi, c_lo)) {  // balanced cohort: one constant, the larger (LV = 1)
         q.c_d = 0.0f;
         q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
@@ -466,7 +468,7 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
     a.cct = d_cct;
     a.ticket = nullptr; a.first_gen = 0; a.stagger_ticks = 0;
     a.lg_n = (float)(std::log2((double)(n_individs ? n_individs : 1u)) * 1.000001) + 1.0e-5f;
-    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const bool pre = prefilter && d_marf;
     const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
     // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)

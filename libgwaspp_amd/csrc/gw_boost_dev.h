@@ -182,6 +182,7 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
 //   measure (check_upper_bound), as it checks the second level.
 struct QuadBound {
     float p, c_m, c_d, k0, c27;  // c27 = 27 max(c_lo, c_hi); c_m == 0: no first level
+    float n48, n72;              // 48 n and 7.2 n (rounded up): the error bound as three multiply-adds
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
 // TWO = false: one curvature constant for both sides (the host sets c_m = max(c_lo, c_hi), c_d = 0 -- what a balanced
@@ -211,7 +212,7 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
     const float A0 = __builtin_fmaf(qb.c_m, q_m, qb.k0);
     const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
     const float r = 1.3862943611198906f * (((A1 + f1.ki) + f2.kj) + n * lt);  // 2 ln 2
-    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, n * (48.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
+    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(6.0f, fabsf(r), __builtin_fmaf(qb.n72, fabsf(lt), qb.n48)));
     return r;
 }
 __device__ __forceinline__ float boost_bound_quad(const uint32_t (&ca)[9], const uint32_t (&co)[9],

@@ -203,8 +203,13 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
 
     // ---- per pair (C layout as in k_boost_mfma); pair p = 16 ta + reg
-    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + wy * WA + 4u * fh;
+    const uint32_t li_base = wy * WA + 4u * fh;  // the lane's first row within the workgroup's 2 WA rows
+    const uint32_t j = b0 + wx * 32u + fr, i_base = a0 + li_base;
     const bool j_ok = j < b_end;
+    // pair p = row i_base + off(p): valid <=> i < a_end, j < b_end, i < j <=> off(p) < limit -- one compare with a constant
+    const uint32_t lim_abs = j_ok ? min(j, a_end) : 0u;
+    const uint32_t limit = lim_abs > i_base ? lim_abs - i_base : 0u;
+    const uint32_t *s_row_lane = s_row + li_base * RS;  // ... and its staged margins at a constant offset from here
     const SnpMargin *pm2 = a.mar + (j_ok ? j : b_end - 1u);
     uint32_t f2c[3], f2t[3];
 #pragma unroll
@@ -254,15 +259,16 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     // measured slower, 84.5 vs 82.8 ms in alternating processes on one box: profiles/r03_c5_experiments.txt)
     static_for<0, 16 * TA>([&](auto pc) {
         constexpr int p = decltype(pc)::value, ta = p >> 4, r = p & 15;
-        const uint32_t i = row_of(p);
-        if (i < a_end && j_ok && i < j) {
+        constexpr uint32_t off = (uint32_t)((p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2));  // row_of(p) - i_base
+        const uint32_t i = i_base + off;
+        if (off < limit) {
             ++n_valid;
 #ifdef GW_FP4_NO_BOUND   // measurement only (tools/build_variant_file.sh): the launch without any per-pair work
             if (a.n_individs < 0) {
 #else
             if (PRE) {
 #endif
-                const uint32_t *rw = s_row + (i - a0) * RS;
+                const uint32_t *rw = s_row_lane + off * RS;
                 SnpMarginF f1;  // the fields the bounds of tables without / with missing calls read
                 if constexpr (NV == 2) {
 #pragma unroll
