@@ -482,7 +482,7 @@ def main():
         out = bench_pairs(args, rank, world, local_rank, dist, comm=comm)
         if comm is not None:
             comm.close()
-        if world > 1:
+        if world > 1 or solo_dist:
             dist.barrier()
             dist.destroy_process_group()
         if out is not None:
