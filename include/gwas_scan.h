@@ -385,10 +385,12 @@ typedef enum gw_option {
                                 gather runs beside the next scan sets a few: RCCL's kernel (37 664 B of LDS, up to
                                 512 threads of 248 VGPRs) cannot share a CU with a long-row scan workgroup, and a
                                 scan workgroup that has to wait for one finishes its static share of the rows late */
-    GW_OPT_BOOST_FP4 = 18,   /* pair screen, tables without a missing call and case groups < 65 536: 1 (default) the four corners
-                                counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 operands -- an operand dword carries 8
-                                samples (one per nibble) and an MFMA 64 per lane, twice the int8 form's, exact counts in
-                                FP32 accumulators (k_boost_mfma_fp4); 0 the int8 form (k_boost_mfma_seq<., 2, 2>) */
+    GW_OPT_BOOST_FP4 = 18,   /* pair screen: 1 (default) the pair tables counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4
+                                operands -- an operand dword carries 8 samples (one per nibble) and an MFMA 64 per lane,
+                                twice the int8 form's, exact counts in FP32 accumulators: k_boost_mfma_fp4 for case groups
+                                < 65 536 (four corners, or nine cells for tables with missing calls), k_boost_mfma_fp4_both
+                                for larger case groups of tables without a missing call (cohorts < 2^24); 0 the int8
+                                forms (k_boost_mfma_seq, k_boost_mfma) */
     GW_OPT_BOOST_FIRST_LEVEL = 19, /* pre-filtered pair screen on the FP4 four-corner kernel: 1 (default) a logarithm-free
                                 upper bound of the measure first (the binary entropy of every cell replaced by a quadratic
                                 that lies below it: nine v_rcp_f32, a third of the vector work; measure <= bound1 + err1,

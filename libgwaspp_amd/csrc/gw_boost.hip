@@ -506,6 +506,13 @@ hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc,
         note(fast ? "gw::k_boost_mfma_seq<%s, 2, 2, false>" : "gw::k_boost_mfma_seq<%s, 3, 1, false>", tp, "");
         return fast ? launch_boost_mfma_seq4(a, pre, stream) : launch_boost_mfma_seq9(a, pre, stream);
     }
+    // tables without a missing call, case groups of any size: the FP4 kernel with both groups' accumulators in registers
+    // (the counts are exact in FP32 below 2^24)
+    if (d_cct && d_marf && fast && fp4 && n_individs < (1u << 24)) {
+        if (pre && first_level && (threshold >= 25.0 || d_dense)) a.quad = quad_bound_constants(n_cases, n_individs);
+        note("gw::k_boost_mfma_fp4_both<%s, %s>", tp, a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
+        return launch_boost_mfma_fp4_both(a, pre, stream);
+    }
     if (d_cct && fast) {  // any group size, 2 waves per SIMD
         note("gw::k_boost_mfma<%s>", tp, "");
         return launch_boost_mfma_both4(a, pre, stream);

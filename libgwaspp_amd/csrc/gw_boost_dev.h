@@ -325,5 +325,6 @@ hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stre
 hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
 hipError_t launch_boost_mfma_lut4(const BoostArgs &a, int compute_units, hipStream_t stream);     // gw_boost_lut4.hip
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream);    // gw_boost_fp4.hip
+hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, hipStream_t stream);          // gw_boost_fp4.hip
 
 }  // namespace gw

@@ -25,13 +25,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // NV = 2, TA = 2: the four corners on 64 x 32 pairs per wave (tables without a missing call);
 // NV = 3, TA = 1: all nine cells on 32 x 32 pairs per wave (tables with missing calls), as k_boost_mfma_seq<., 3, 1>
 // LV: the first-level bound -- 0 none, 1 one curvature constant (balanced cohorts), 2 two-piece quadratic
-template <bool PRE, int NV, int TA, int LV>
-__global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
+// BOTH: the case counts stay in registers beside the control counts instead of being parked in LDS as uint16 -- case
+// groups of 65 536 and more (k_boost_mfma_fp4_both: NV = 2, TA = 1, the 128 accumulator registers split between the groups)
+template <bool PRE, int NV, int TA, int LV, bool BOTH>
+__device__ __forceinline__ void fp4_pair_tile(const BoostArgs &a) {
     constexpr bool L1 = LV != 0;
     constexpr int NP = NV * NV;            // products per tile pair
     constexpr int NT = TA * NP;            // accumulator tiles
     constexpr int WA = 32 * TA;            // A rows per wave
-    __shared__ uint32_t s_case[NT * 8 * 256];  // [tile][register pair][thread]: two uint16 case counts
+    __shared__ uint32_t s_case[BOTH ? 1 : NT * 8 * 256];  // [tile][register pair][thread]: two uint16 case counts
     // PRE: what the per-pair bound needs of the workgroup's 2 WA rows -- genotype counts of the two groups, P(status | g)
     // and K_i -- staged once: the bound reads 13 dwords per pair, and as loads from global memory (two rows per wave
     // instruction, ~10 instructions per pair at two waves per SIMD) their latency, not the arithmetic, set its pace
@@ -192,13 +194,19 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
         });
     };
     for (uint32_t c0 = 0; c0 < nchunk_c; c0 += RING) round(c0);
+    f32x16 acc_case[BOTH ? TA : 1][BOTH ? NP : 1];
 #pragma unroll
     for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-        for (int c = 0; c < NP; ++c)
+        for (int c = 0; c < NP; ++c) {
+            if constexpr (BOTH) {
+                acc_case[ta][c] = acc[ta][c];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2)
-                s_case[((ta * NP + c) * 8 + (r >> 1)) * 256 + t] = (uint32_t)acc[ta][c][r] | ((uint32_t)acc[ta][c][r + 1] << 16);
+                for (int r = 0; r < 16; r += 2)
+                    s_case[((ta * NP + c) * 8 + (r >> 1)) * 256 + t] = (uint32_t)acc[ta][c][r] | ((uint32_t)acc[ta][c][r + 1] << 16);
+            }
+        }
     clear();
     for (uint32_t c0 = nchunk_c; c0 < nchunk; c0 += RING) round(c0);
 
@@ -227,8 +235,15 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
         else return boost_bound(ca, co, f1, mf2, nf, inv_n, err);
     };
     auto case_count = [&](int tile, int r) -> uint32_t {  // r may be a run-time value
-        const uint32_t v = s_case[(tile * 8 + (r >> 1)) * 256 + t];
-        return (r & 1) ? v >> 16 : v & 0xFFFFu;
+        if constexpr (BOTH) {
+            float x = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16 * NT; ++q) x = (tile * 16 + r) == q ? acc_case[(q >> 4) / NP][(q >> 4) % NP][q & 15] : x;
+            return (uint32_t)x;
+        } else {
+            const uint32_t v = s_case[(tile * 8 + (r >> 1)) * 256 + t];
+            return (r & 1) ? v >> 16 : v & 0xFFFFu;
+        }
     };
     auto row_of = [&](int p) { return i_base + (uint32_t)((p >> 4) * 32 + (p & 3) + 8 * ((p & 15) >> 2)); };
     // the two 3 x 3 tables of a pair from its counted cells (cells[0] cases, [1] controls)
@@ -285,7 +300,8 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
                     constexpr int at[4] = {0, 2, 6, 8};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        fx[at[c]] = (float)case_count(ta * NP + c, r);
+                        if constexpr (BOTH) fx[at[c]] = acc_case[ta][c][r];
+                        else fx[at[c]] = (float)case_count(ta * NP + c, r);
                         fs[at[c]] = fx[at[c]] + acc[ta][c % NP][r];
                     }
                     const float rx0 = __uint_as_float(rw[0]), rx2 = __uint_as_float(rw[1]);
@@ -380,6 +396,25 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
     }
 }
 
+
+template <bool PRE, int NV, int TA, int LV>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4(BoostArgs a) {
+    fp4_pair_tile<PRE, NV, TA, LV, false>(a);
+}
+// case groups of any size (counts exact in the FP32 accumulators below 2^24): four corners, both groups' accumulators kept
+template <bool PRE, int LV>
+__global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4_both(BoostArgs a) {
+    fp4_pair_tile<PRE, 2, 1, LV, true>(a);
+}
+
+hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, hipStream_t stream) {
+    const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+    if (pre && a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 2>), grid, dim3(256), 0, stream, a);
+    else if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 1>), grid, dim3(256), 0, stream, a);
+    else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 0>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_boost_mfma_fp4_both<false, 0>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream) {
     if (nine) {

@@ -250,7 +250,7 @@ def _quad_constants(n_cases, n):
 
 @pytest.mark.parametrize("n,m,case_share,low_maf", [(600, 48, 0.5, False), (6000, 64, 0.45, True), (6000, 48, 0.15, False),
                                                     (40_000, 40, 0.5, False), (40_000, 36, 0.85, True),
-                                                    (250_000, 24, 0.25, False)])
+                                                    (250_000, 24, 0.25, False), (250_000, 24, 0.3, False)])
 def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m, case_share, low_maf):
     """GW_OPT_BOOST_FIRST_LEVEL (k_boost_mfma_fp4<true, 2, 2, 1 or 2>): the logarithm-free bound of gw_boost_dev.h
     boost_bound_quad.  For every pair: measure <= bound1 + err1 (what the screen relies on); the device's value lies
@@ -272,6 +272,8 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
     _, ct, nt = oracle.ccs_masks(ctrls, n)
     n_sel = nc + nt
     p, c_lo, c_hi, k0, level = _quad_constants(nc, n_sel)
+    # case groups of 65 536 and more: the kernel that keeps both groups' accumulators in registers
+    kname = (lambda lv: f"gw::k_boost_mfma_fp4_both<true, {lv}>") if nc >= 65536 else (lambda lv: f"gw::k_boost_mfma_fp4<true, 2, 2, {lv}>")
     c = max(c_lo, c_hi)
     z = np.linspace(0.0, 1.0, 200_001)
     ent = lambda v: -(np.where(v > 0, v * np.log2(np.maximum(v, 1e-300)), 0.0) + np.where(v < 1, (1 - v) * np.log2(np.maximum(1 - v, 1e-300)), 0.0))
@@ -292,7 +294,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
         exact = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 4)
         b1 = t.boost_measures(0, m, 0, m)
-        assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {level}>"
+        assert t.last_boost_kernel() == kname(level)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 5)
         e1 = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
@@ -322,7 +324,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
                 t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, first)
                 hits, n_hits, n_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
                 # (the first level is only used where it is selective: thresholds of 25 and more)
-                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 2, 2, {level if first and thr >= 25.0 else 0}>"
+                assert t.last_boost_kernel() == kname(level if first and thr >= 25.0 else 0)
                 assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
                 assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
         t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, 1)
@@ -428,6 +430,40 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
         t.set_option(gw.capi.OPT_BOOST_LUT, 1)
         t.boost_screen(0, 100, 0, 100, extremes=False)
         assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0>"   # nine cells: never the LUT form
+
+
+@pytest.mark.parametrize("n,m,force", [(3000, 200, True), (9000, 131, True), (140_000, 90, False), (200_000, 70, False)])
+def test_fp4_both_groups_kernel_equals_the_int8_and_vector_kernels(n, m, force):
+    """k_boost_mfma_fp4_both: case groups of 65 536 and more (or GW_OPT_BOOST_MATRIX_CORES = 2) on tables without a missing
+    call keep both groups' FP32 accumulators in registers instead of parking uint16 case counts in LDS.  Every pair's FP64
+    measure, the extremes and the hit lists with and without the pre-filter must be those of the int8 both-groups kernel
+    (k_boost_mfma) and of the vector-ALU kernel, bit for bit."""
+    with gw.GwTable(n, m) as t:
+        t.simulate(29, 5, 0, exact=True)
+        t.simulate_phenotype(29)
+        res = {}
+        for name, (fp4, mfma) in {"fp4": (1, 2 if force else 1), "int8": (0, 2 if force else 1), "valu": (0, 0)}.items():
+            t.set_option(gw.capi.OPT_BOOST_FP4, fp4)
+            t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mfma)
+            dense = t.boost_measures(0, m, 0, m)
+            k_dense = t.last_boost_kernel()
+            hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=8.0)
+            pre_hits, pre_nh, pre_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=8.0, extremes=False)
+            k_pre = t.last_boost_kernel()
+            hi_hits, hi_nh, *_ = t.boost_screen(3, m - 3, 1, m - 1, threshold=26.0, extremes=False)   # first level in use
+            res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin,
+                         np.sort(pre_hits, order=["snp_a", "snp_b"]), pre_nh, pre_pairs, np.sort(hi_hits, order=["snp_a", "snp_b"]), hi_nh,
+                         k_dense, k_pre, t.last_boost_kernel())
+        assert res["fp4"][11] == "gw::k_boost_mfma_fp4_both<false, 0>" and res["fp4"][12] == "gw::k_boost_mfma_fp4_both<true, 0>"
+        assert res["fp4"][13] in ("gw::k_boost_mfma_fp4_both<true, 1>", "gw::k_boost_mfma_fp4_both<true, 2>")
+        assert res["int8"][11] == "gw::k_boost_mfma<false>" and res["int8"][12] == "gw::k_boost_mfma<true>"
+        for other in ("int8", "valu"):
+            assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
+            for k in (1, 6, 9):
+                assert np.array_equal(res["fp4"][k], res[other][k])
+            assert res["fp4"][2:6] == res[other][2:6] and res["fp4"][7:9] == res[other][7:9] and res["fp4"][10] == res[other][10]
+        assert np.array_equal(res["fp4"][1], res["fp4"][6])          # pre-filter on / off: the same list
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
 
 
 @pytest.mark.parametrize("missing", [0, 655])
