@@ -1,20 +1,25 @@
-// gw_boost_fp4.hip -- k_boost_mfma_fp4<PRE, NV, TA>: the pair kernels for case groups < 65 536 (four corners for tables
-// without a missing call, nine cells otherwise) with the pair tables counted by v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 (E2M1) operands.
+// gw_boost_fp4.hip -- the pair kernels that count the pair tables with v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 (E2M1) operands:
+//   k_boost_mfma_fp4<PRE, NV, TA, LV>   case groups < 65 536: four corners (NV = 2, TA = 2; tables without a missing call) or
+//                                       nine cells (NV = 3, TA = 1), one group at a time, the case counts parked in LDS as uint16
+//   k_boost_mfma_fp4_both<PRE, LV>      case groups of any size (cohorts < 2^24), four corners, both groups' accumulators in registers
+// LV: the logarithm-free first-level bound ahead of the bound proper (gw_boost_dev.h boost_bound_quad): 0 none, 1 / 2.
 //
 // k_boost_mfma_seq<PRE, 2, 2> (gw_boost_seq.inc) is bound by in-order issue: an int8 MFMA covers 32 samples per lane and
 // needs eight operand dwords made by one vector instruction each (4 samples per dword, one per byte) -- 25-27 of the
 // 32 cycles the matrix core takes go to issuing the MFMA and its operand expansion (profiles/r03_c5_experiments.txt).
 // FP4 halves both: an operand dword carries EIGHT samples, one per nibble, and one MFMA covers 64 per lane in the same
-// 32 cycles.  The expansion stays a single v_and / v_bitop3: dword = class word & (0x11111111 << k) leaves the FP4 values
-// 0.5 (k = 0), 1 (k = 1), 2 (k = 2) in the nibbles; k = 3 would be the sign bit, so that one is (word >> 3) & 0x11111111
-// (0.5).  No bit reversal on the B side: all four dwords of an operand use the SAME k (one dword from each of four words,
-// i.e. two 64-sample units = two chunks of the block-tiled table per MFMA), so every product of an MFMA carries the same
-// weight 4^(k-1), and the instruction's own E8M0 block scales (byte 0 of a VGPR per operand: 128 / 127 / 126 = 2 / 1 /
-// 0.5) put it back to exactly 1.  Accumulators are FP32 and hold the counts exactly (< 2^24).  tools/fp4_probe.hip is the
-// 32 x 32 x 256 check of all of this against popcounts.
-// Per pair of chunks (256 samples per row): 32 MFMAs (64 before) and 120 expansion instructions (264 before).
-// Everything else -- one group at a time, the case counts parked in LDS as uint16, the per-pair split-log bound and the
-// FP64 measure -- is k_boost_mfma_seq's; hits and measures are bit-identical.
+// 32 cycles.  The expansion is a single v_bitop3: dword = class of the two plane words & (0x11111111 << k) leaves the FP4
+// values 0.5 (k = 0), 1 (k = 1), 2 (k = 2) in the nibbles; k = 3 would be the sign bit, so for that group the PLANES are
+// shifted down by 3 once and treated like k = 0 (0.5).  No bit reversal on the B side: all four dwords of an operand use
+// the SAME k (one dword from each of four words, i.e. two 64-sample units = two chunks of the block-tiled table per MFMA),
+// so every product of an MFMA carries the same weight 4^(k-1), and the instruction's own E8M0 block scales (byte 0 of a
+// VGPR per operand: 128 / 127 / 126 = 2 / 1 / 0.5) put it back to exactly 1.  Accumulators are FP32 and hold the counts
+// exactly (< 2^24).  tools/fp4_probe.hip is the 32 x 32 x 256 check of all of this against popcounts;
+// tools/mfma_rate_probe.hip measures what the matrix cores sustain for this instruction and how many vector instructions
+// per MFMA are free (about five; the counting loop issues 4.3).
+// Per pair of chunks (256 samples per row): 32 MFMAs (64 with int8) and 120 expansion instructions (264).
+// The per-pair work: first-level bound -> boost_bound_split -> FP64 measure; hits and measures are bit-identical to the
+// int8 and vector-ALU kernels'.
 #include "gw_boost_dev.h"
 
 namespace gw {
