@@ -45,9 +45,29 @@ __device__ __forceinline__ void fp4_pair_tile(const BoostArgs &a) {
     constexpr int RS = NV == 3 ? 20 : 16;  // dwords per staged row (nine-cell tables: 1 / P(status | g) as well)
     __shared__ uint32_t s_row[PRE ? 2 * WA * RS : 1];
 
-    const uint32_t a0 = a.a_begin + blockIdx.y * (2 * WA), b0 = a.b_begin + blockIdx.x * MT;
+    // Tile order.  The grid is (column tiles padded to a multiple of 8) x (row tiles); workgroups are dispatched x-fastest and
+    // dealt round-robin to the 8 XCDs, so an XCD sees the column tiles bx = xcd (mod 8) of row tile 0, then of row tile 1, ...
+    // and every 160 KB column tile has left its 4 MB L2 long before the next row tile asks for it again.  The XCD-local
+    // sequence number l is re-read as: GW_FP4_ROW_GROUP row tiles per column tile, then the next column tile -- the same
+    // set of tiles per XCD, but a column tile now serves G consecutive workgroups.
+    // (measured at c5, alternating processes on one box: G = 1 72.2, 2 70.8, 4 70.1, 6 69.7 - 69.8, 8 69.8 - 69.9, 12 71.5,
+    // 16 74.4 ms: 6 row tiles of 128 rows, i.e. ~2 MB of operand rows per group)
+#ifndef GW_FP4_ROW_GROUP
+#define GW_FP4_ROW_GROUP (12 / TA)
+#endif
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (GW_FP4_ROW_GROUP > 1 && (gridDim.x & 7u) == 0u) {
+        constexpr uint32_t G = GW_FP4_ROW_GROUP;
+        const uint32_t nc = gridDim.x >> 3, xcd = bx & 7u, l = by * nc + (bx >> 3);
+        const uint32_t grp = l / (G * nc), rem = l - grp * (G * nc);
+        const uint32_t g_here = min(G, gridDim.y - grp * G);  // the last group may be short
+        const uint32_t vxl = rem / g_here;
+        by = grp * G + (rem - vxl * g_here);
+        bx = vxl * 8u + xcd;
+    }
+    const uint32_t a0 = a.a_begin + by * (2 * WA), b0 = a.b_begin + bx * MT;
     const uint32_t a_end = a.a_begin + a.n_a, b_end = a.b_begin + a.n_b;
-    if (a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;
+    if (b0 >= b_end || a0 + 1u >= min(b0 + (uint32_t)MT, b_end)) return;  // grid padding; wholly on or below the diagonal
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t wy = wave >> 1, wx = wave & 1u;
@@ -413,7 +433,7 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma_fp4_both(BoostArgs a) {
 }
 
 hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, hipStream_t stream) {
-    const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+    const dim3 grid(((a.n_b + MT - 1) / MT + 7u) & ~7u, (a.n_a + MT - 1) / MT);
     if (pre && a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 2>), grid, dim3(256), 0, stream, a);
     else if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 1>), grid, dim3(256), 0, stream, a);
     else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 0>), grid, dim3(256), 0, stream, a);
@@ -423,11 +443,11 @@ hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, hipStream_t 
 
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream) {
     if (nine) {
-        const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+        const dim3 grid(((a.n_b + MT - 1) / MT + 7u) & ~7u, (a.n_a + MT - 1) / MT);
         if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, 0>), grid, dim3(256), 0, stream, a);
     } else {
-        const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + 2 * MT - 1) / (2 * MT));
+        const dim3 grid(((a.n_b + MT - 1) / MT + 7u) & ~7u, (a.n_a + 2 * MT - 1) / (2 * MT));
         if (pre && a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 2>), grid, dim3(256), 0, stream, a);
         else if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 1>), grid, dim3(256), 0, stream, a);
         else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 0>), grid, dim3(256), 0, stream, a);

@@ -82,18 +82,29 @@ def test_two_ranks_scan_their_shards_on_the_gpu_and_gather(n, total, missing, n_
     from libgwaspp_amd import shard
     world, seed = 2, 0x5EED
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, missing, n_chunks, q))
-             for r in range(world)]
-    for p in procs:
-        p.start()
-    try:
-        chunks, bounds, kernel = q.get(timeout=600)
-    finally:
+    import queue as _queue
+    for attempt in range(2):   # a second try with another port if the rendezvous itself fails (the port is picked, then bound later)
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, missing, n_chunks, q))
+                 for r in range(world)]
         for p in procs:
-            p.join(timeout=120)
-    assert all(p.exitcode == 0 for p in procs)
+            p.start()
+        result = None
+        try:
+            result = q.get(timeout=600)
+        except _queue.Empty:
+            pass
+        finally:
+            for p in procs:
+                p.join(timeout=120)
+                if p.is_alive():
+                    p.kill()
+        if result is not None and all(p.exitcode == 0 for p in procs):
+            break
+        print(f"attempt {attempt}: exit codes {[p.exitcode for p in procs]}, result {'present' if result is not None else 'missing'}")
+    assert result is not None and all(p.exitcode == 0 for p in procs)
+    chunks, bounds, kernel = result
     assert kernel.startswith("gw::k_scan_cc")
     # the single-process scan of the whole table
     with gw.GwTable(n, total) as t:
