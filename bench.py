@@ -53,6 +53,7 @@ WORKLOADS = {
 }
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA: 2x the ~2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, matrix cores)
 MFMA_FP4_PEAK_TOPS = 10000.0  # dense FP4 / FP6 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): 4x bf16 per clock (same table)
+MFMA_FP4_STREAM_TOPS = 8900.0   # measured: a pure stream of v_mfma_scale_f32_32x32x64_f8f6f4 (profiles/r03_mfma_rate_probe.txt)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 0x5EED
 RECORD_BYTES = 32 + 64  # counts uint32[8] + stats float64[8] per SNP
@@ -393,6 +394,9 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
                                  ("FP4 MFMA (the operands are FP4: one sample per nibble)" if fp4 else "int8 MFMA"),
                          "frac": 2.0 * macs / per_step / 1e12 / peak,
                          "frac_of_int8_peak": 2.0 * macs / per_step / 1e12 / MFMA_I8_PEAK_TOPS,
+                         # what a pure stream of this MFMA sustained on one MI355X (tools/mfma_rate_probe.hip,
+                         # profiles/r03_mfma_rate_probe.txt): informational, `peak` stays the guide's dense figure
+                         "mfma_stream_sustained_TOPs": (MFMA_FP4_STREAM_TOPS if fp4 else None),
                          "traffic": c5_traffic[0], "traffic_source": c5_traffic[1],
                          "kernel": kernel_name, "kernel_ms": kernel_ms_total / steps,
                          "launches_per_step": len(blocks),
