@@ -460,13 +460,26 @@ def main():
     solo_dist = args.dist_with_one_rank and world == 1
     if world > 1 or solo_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        # Under a launcher MASTER_ADDR / MASTER_PORT come from it (env://).  Started by hand with one rank there is no
+        # launcher and no port worth picking: the store is a file in a directory of this process's own.
+        rdzv_dir = None
+        if "MASTER_PORT" in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            init = {}
+        elif world == 1:
+            import atexit
+            import shutil
+            import tempfile
+            rdzv_dir = tempfile.mkdtemp(prefix="gw_bench_rdzv_")
+            atexit.register(shutil.rmtree, rdzv_dir, True)
+            init = {"init_method": "file://" + os.path.join(rdzv_dir, "store")}
+        else:
+            raise SystemExit("bench.py: WORLD_SIZE > 1 without MASTER_PORT -- start the ranks with torch.distributed.run")
         if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, **init)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", local_rank), **init)
 
     comm = None
     if args.exchange == "capi" and not (args.rehearse_on_one_gpu and world > 1):

@@ -5,7 +5,6 @@ memory), each rank generates and scans its own contiguous SNP shard of ONE table
 compared byte for byte with a single-process scan of the whole table.  Needs a real MI355X: pytest -m gpu."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -26,23 +25,14 @@ def _need_gpu():
         pytest.fail("no HIP device visible: the gpu tests must run on the GPU box")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, total, n, seed, missing, n_chunks, q):
+def _worker(rank, world, rdzv, total, n, seed, missing, n_chunks, q):
     sys.path.insert(0, ROOT)
     import torch                      # before the first call into libgwscan.so (see capi.py)
     import torch.distributed as dist
     import libgwaspp_amd as gw
     from libgwaspp_amd import shard
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file under the test's tmp_path: nobody picks a port, so nobody can lose one
+    dist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         begin, end = shard.snp_range(total, rank, world)
@@ -77,33 +67,25 @@ def _worker(rank, world, port, total, n, seed, missing, n_chunks, q):
 
 @pytest.mark.parametrize("n,total,missing,n_chunks", [(10_000, 20_001, 655, 1), (100_000, 3_001, 0, 2),
                                                        (500_000, 1_501, 0, 2)])
-def test_two_ranks_scan_their_shards_on_the_gpu_and_gather(n, total, missing, n_chunks):
+def test_two_ranks_scan_their_shards_on_the_gpu_and_gather(n, total, missing, n_chunks, tmp_path):
     import torch.multiprocessing as mp
     from libgwaspp_amd import shard
     world, seed = 2, 0x5EED
     ctx = mp.get_context("spawn")
-    import queue as _queue
-    for attempt in range(2):   # a second try with another port if the rendezvous itself fails (the port is picked, then bound later)
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, missing, n_chunks, q))
-                 for r in range(world)]
+    q = ctx.Queue()
+    rdzv = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_worker, args=(r, world, rdzv, total, n, seed, missing, n_chunks, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        result = q.get(timeout=600)
+    finally:
         for p in procs:
-            p.start()
-        result = None
-        try:
-            result = q.get(timeout=600)
-        except _queue.Empty:
-            pass
-        finally:
-            for p in procs:
-                p.join(timeout=120)
-                if p.is_alive():
-                    p.kill()
-        if result is not None and all(p.exitcode == 0 for p in procs):
-            break
-        print(f"attempt {attempt}: exit codes {[p.exitcode for p in procs]}, result {'present' if result is not None else 'missing'}")
-    assert result is not None and all(p.exitcode == 0 for p in procs)
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     chunks, bounds, kernel = result
     assert kernel.startswith("gw::k_scan_cc")
     # the single-process scan of the whole table
@@ -127,8 +109,10 @@ def test_two_ranks_scan_their_shards_on_the_gpu_and_gather(n, total, missing, n_
 
 
 def _torchrun(extra, nproc=2):
+    """The launcher binds its own rendezvous socket (c10d store on port 0, held by the agent for the whole job and
+    handed to the workers as MASTER_PORT): no port number exists before a socket is bound to it."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1",
            os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
 

@@ -4,7 +4,6 @@ from the oracle on its shard of the synthetic table (global SNP index =
 shard begin + row, as bench.py generates them); rank 0 checks the gathered
 result against a single-process scan of the whole range."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -14,12 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RECORD = 96
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _init_gloo(dist, rdzv, rank, world):
+    """Rendezvous through a file in the test's own tmp_path: no port is picked by anyone, so none can be taken."""
+    dist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world)
 
 
 def _records(oracle, seed, begin, count, n):
@@ -30,15 +26,13 @@ def _records(oracle, seed, begin, count, n):
     return np.concatenate([counts.view(np.uint8).reshape(-1), stats.view(np.uint8).reshape(-1)])
 
 
-def _worker(rank, world, port, total, n, seed, q):
+def _worker(rank, world, rdzv, total, n, seed, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     from libgwaspp_amd import shard
     from oracle import oracle
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_gloo(dist, rdzv, rank, world)
     try:
         sizes = []
         for r in range(world):
@@ -97,13 +91,13 @@ def test_pair_row_blocks_cover_the_triangle_once():
                 assert max(pairs) / (sum(pairs) / world) < 1.02   # balanced
 
 
-def test_two_rank_gather_equals_single_process(oracle):
+def test_two_rank_gather_equals_single_process(oracle, tmp_path):
     import torch.multiprocessing as mp
     world, total, n, seed = 2, 37, 3000, 0x5EED
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, seed, q)) for r in range(world)]
+    rdzv = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_worker, args=(r, world, rdzv, total, n, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
     got, chunked, bounds = q.get(timeout=120)
