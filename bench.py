@@ -305,6 +305,7 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
     list_bytes = capi.BOOST_LIST_HEADER_BYTES + 16 * cap
     d_list = torch.zeros(list_bytes, dtype=torch.uint8, device="cuda")
     d_all = torch.zeros(world * list_bytes, dtype=torch.uint8, device="cuda") if (world > 1 or comm is not None) else d_list
+    torch.cuda.synchronize()   # the zero fills ran on torch's default stream; everything below runs on `stream`
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream

@@ -48,7 +48,10 @@ def _worker(rank, world, rdzv, total, n, seed, missing, n_chunks, q):
             for c in range(len(bounds) - 1):
                 rows_cap = bounds[c + 1] - bounds[c]
                 lo, hi = min(bounds[c], n_local), min(bounds[c + 1], n_local)
-                buf = torch.zeros(rows_cap * RECORD, dtype=torch.uint8, device="cuda")
+                # zero-filled ON the scan's stream: filled on torch's default stream it would race with the scan (the fill
+                # can land after the records; seen once on the GPU box as zeros in a gathered chunk)
+                with torch.cuda.stream(stream):
+                    buf = torch.zeros(rows_cap * RECORD, dtype=torch.uint8, device="cuda")
                 base = buf.data_ptr()
                 if hi > lo:
                     t.scan_case_control_device(lo, hi - lo, base, base + rows_cap * 32, stream.cuda_stream)

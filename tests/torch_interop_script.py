@@ -25,6 +25,7 @@ want_dist = [t.scan_distribution() for t in tables]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 bufs = [torch.zeros(m * 96, dtype=torch.uint8, device="cuda") for _ in range(2)]
 dists = [torch.zeros(m * 4, dtype=torch.int32, device="cuda") for _ in range(2)]
+torch.cuda.synchronize()                                   # the fills ran on torch's default stream, the scans will not
 for rep in range(3):                                       # interleave launches of both tables
     for k, t in enumerate(tables):
         with torch.cuda.stream(streams[k]):
@@ -42,6 +43,7 @@ for k in range(2):
 out["device_pointer_forms_match_host_forms"] = ok
 # counts-only form writes nothing to the stats pointer
 buf = torch.full((m * 96,), 0xAB, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()                                   # (same: the fill must have landed before the scan writes)
 tables[0].scan_case_control_device(0, m, buf.data_ptr(), None, streams[0].cuda_stream)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy()
