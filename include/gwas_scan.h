@@ -398,14 +398,18 @@ typedef enum gw_option {
                                 10 000 it lets through, the FP64 measure for what passes both -- the hit list is that of
                                 the all-FP64 screen; 0 the bound proper for every pair.  GW_OPT_BOOST_PREFILTER 4 / 5
                                 (diagnostic): gw_boost_measures returns the first-level bound / its error bound */
-    GW_OPT_BOOST_LUT = 17,   /* pair screen of cohorts with at most 16 383 selected individuals and no missing call:
-                                1 = the persistent kernel whose single-precision bound looks its 27 logarithms up in an LDS
-                                table of k log2 k (k_boost_mfma_lut; an experiment of round 3: fewer vector instructions,
-                                but 123 vs 117 ms on config 5); 0 (default) the one-group-at-a-time kernel */
-    GW_OPT_BOOST_STAGGER_US = 16, /* pair screen, one-group-at-a-time MFMA kernels: microseconds the workgroups in odd wave
-                                slots of the FIRST generation wait before they start, so that the two workgroups of a
-                                CU are out of step from then on (one's per-pair evaluation on the vector ALU runs under the
-                                other's counting on the matrix cores).  -1 (default) auto, 0 off; get returns the value in use */
+    GW_OPT_BOOST_LUT = 17,   /* RETIRED in round 4 (number kept): the LDS-table pair kernel of round 3, measured slower
+                                (123 vs 117 ms on config 5), is no longer in the library (tools/experiments/); setting a
+                                non-zero value is GW_E_INVALID, get returns 0 */
+    GW_OPT_BOOST_STAGGER_US = 16, /* RETIRED in round 4 (number kept): the start-up stagger of co-resident workgroups
+                                measured no effect; setting a positive value is GW_E_INVALID, get returns 0 */
+    GW_OPT_BOOST_CANDIDATES = 20, /* pre-filtered pair screen on the FP4 kernels: the pairs the in-kernel bound cannot rule out
+                                go to a candidate list in HBM (40 B each; 80 B for tables with missing calls) and get their
+                                second-level bound / FP64 measure from a finishing kernel.  0 (default) auto = one record
+                                per 64 pairs of the block pair + 65 536, at least 2^20 (never more than one per pair), at
+                                most 32 M; > 0 that many records.  A block
+                                whose candidates do not fit is repeated with every pair in FP64 (counted by
+                                GW_OPT_BOOST_PREFILTER_TRIPS), so the value bounds cost, never results */
     GW_OPT_DEFER_RECORDS = 15, /* rows up to ~100 k samples: 1 = nothing is written while the table is being read; a wave
                                 parks the six sums of its finished rows in LDS and, after its last row, runs the FP64
                                 epilogue over all of them and writes its records in one burst (launches are cut

@@ -32,10 +32,11 @@ OPT_COLUMN_SEGMENT = 11
 OPT_BOOST_PREFILTER_TRIPS = 12
 OPT_RESERVE_CUS = 14
 OPT_DEFER_RECORDS = 15
-OPT_BOOST_STAGGER_US = 16
-OPT_BOOST_LUT = 17
+OPT_BOOST_STAGGER_US = 16   # retired (round 4)
+OPT_BOOST_LUT = 17          # retired (round 4)
 OPT_BOOST_FP4 = 18
 OPT_BOOST_FIRST_LEVEL = 19
+OPT_BOOST_CANDIDATES = 20
 
 
 class GwError(RuntimeError):

@@ -11,7 +11,12 @@ That is only correct while the compiler
   * and uses no scratch memory in the kernel.
 
 A compiler bump can break any of these without a CPU-side symptom, so the Makefile runs this on the built
-object and fails the build otherwise.  Usage: check_isa.py build/gw_kernels.o"""
+object and fails the build otherwise.  Usage: check_isa.py build/gw_kernels.o
+
+Second guard (round 4), `check_isa.py --no-scratch build/gw_boost_fp4.o`: the pair kernels the default dispatch of the
+screen reaches (the pre-filtered FP4 kernels and k_boost_finish) must use NO scratch memory -- code-object metadata
+private_segment_fixed_size == 0, no spilled VGPR / SGPR, and not one scratch_ instruction in the ISA.  Round 3's
+kernels spilled 56 - 84 bytes per lane unnoticed (3.7 GB of scratch writes per config-5 launch)."""
 import os
 import re
 import subprocess
@@ -199,5 +204,65 @@ def main(obj):
     return 0
 
 
+def unbundle(obj, d):
+    fat, co = os.path.join(d, "fat"), os.path.join(d, "co")
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.devnull], check=True)
+    subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=" + TARGET,
+                    "--input=" + fat, "--output=" + co], check=True)
+    return co
+
+
+def kernel_metadata(co):
+    """{mangled name: {key: int}} from the code object's AMDGPU metadata note"""
+    text = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, cur = {}, {}
+    for ln in text.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s+(\S+)\s*$", ln)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "agpr_count" and cur.get("name"):   # first key of the next kernel's map
+            out[cur["name"]] = cur
+            cur = {}
+        cur[key] = val
+    if cur.get("name"):
+        out[cur["name"]] = cur
+    return out
+
+
+def main_no_scratch(obj, must_match=r"k_boost_mfma_fp4|k_boost_finish", at_least=9):
+    with tempfile.TemporaryDirectory() as d:
+        co = unbundle(obj, d)
+        meta = kernel_metadata(co)
+        funcs = functions(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True,
+                                         text=True).stdout)
+    checked, failed = 0, 0
+    for name, m in sorted(meta.items()):
+        if not re.search(must_match, name):
+            continue
+        checked += 1
+        problems = []
+        for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count"):
+            if int(m.get(key, "0")) != 0:
+                problems.append(f"{key} = {m[key]}")
+        n_scratch = sum(1 for i in funcs.get(name, {"insts": []})["insts"] if i["op"].startswith("scratch_"))
+        if n_scratch:
+            problems.append(f"{n_scratch} scratch_ instructions")
+        if name not in funcs:
+            problems.append("no ISA found for it")
+        for p in problems:
+            failed += 1
+            print(f"check_isa: {name}: {p}", file=sys.stderr)
+    if checked < at_least:
+        print(f"check_isa: only {checked} kernels matching /{must_match}/ in {obj} (expected {at_least})", file=sys.stderr)
+        return 1
+    if failed:
+        return 1
+    print(f"check_isa: {checked} pair kernels of {os.path.basename(obj)} use no scratch memory")
+    return 0
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--no-scratch":
+        sys.exit(main_no_scratch(sys.argv[2]))
     sys.exit(main(sys.argv[1]))

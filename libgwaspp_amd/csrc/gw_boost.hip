@@ -152,7 +152,29 @@ __global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_in
     }
     f.ki = (float)ki;
     f.kj = (float)kj;
-    f.pad[0] = f.pad[1] = 0.0f;
+    // tao - 1 from the four corners (SnpMarginF::ua, ::vb; the derivation is at boost_bound_quad_f)
+    double ea = 0.0, eb = 0.0;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const double n_grp = (double)(grp == 0 ? n_cases : n_ctrls), pc = n_grp / n;
+        double d[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const uint32_t k = grp == 0 ? m.cases[g] : m.ctrls[g];
+            d[g] = (m.margins[g] && n_grp > 0.0) ? ((double)k / (double)m.margins[g]) / pc - 1.0 : 0.0;
+        }
+        const double u0 = d[0] - d[1], u2 = d[2] - d[1];
+        f.ua[3 * grp + 0] = (float)u0;
+        f.ua[3 * grp + 1] = (float)u2;
+        f.ua[3 * grp + 2] = (float)(n * d[1]);
+        f.vb[3 * grp + 0] = (float)(pc / n * u0);
+        f.vb[3 * grp + 1] = (float)(pc / n * u2);
+        f.vb[3 * grp + 2] = (float)(pc / n * d[1]);
+        ea = fmax(ea, fmax(fmax(fabs(u0), fabs(u2)), fabs(d[1])));
+        eb += pc / n * ((double)m.margins[0] * fabs(u0) + (double)m.margins[2] * fabs(u2) + n * fabs(d[1]));
+    }
+    f.ea = (float)(ea * 1.000001);   // rounded up: they scale an error bound
+    f.eb = (float)(eb * 1.000001);
     marf[r] = f;
 }
 
@@ -422,7 +444,7 @@ hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_
 // c_m / c_d as floats such that c_m - c_d >= c_lo and c_m + c_d >= c_hi.  c_m == 0 (no first level) for a cohort with
 // one group only.
 QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
-    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (n_cases == 0 || n_cases >= n) return q;
     const float pf = (float)((double)n_cases / (double)n);
     if (!(pf > 0.0f && pf < 1.0f)) return q;
@@ -433,7 +455,8 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     const double k0 = -(double)n * h0 - h1 * ((double)n_cases - p * (double)n);
     q.p = pf;
     q.n48 = std::nextafter(48.0f * (float)n, INFINITY);
-    q.n72 = std::nextafter(7.2f * (float)n, INFINITY);
+    q.n30 = std::nextafter(30.0f * (float)n, INFINITY);
+    q.n1 = (float)((double)n * 1.4426950408889634);
     if (std::fabs(c_hi - c_lo) <= 0.02 * std::max(c_hi, c_lo)) {  // balanced cohort: one constant, the larger (LV = 1)
         q.c_d = 0.0f;
         q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
@@ -449,80 +472,59 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     return q;
 }
 
-hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
-                        const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
-                        uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
-                        uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
-                        unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
-                        bool fast, hipStream_t stream, const SnpMarginF *d_marf, bool prefilter,
-                        float bound_threshold, const u32x4 *d_cct, bool both_groups, bool dense_err, char *kernel_name,
-                        unsigned int *d_ticket, uint32_t first_gen, uint32_t stagger_ticks, const float *d_klogk,
-                        uint32_t *d_park, int compute_units, bool fp4, uint32_t n_cases, bool first_level) {
-    if (n_a == 0 || n_b == 0) return hipSuccess;
+hipError_t launch_boost(const BoostLaunch &l) {
+    if (l.n_a == 0 || l.n_b == 0) return hipSuccess;
     BoostArgs a;
-    a.cc = d_cc; a.cc_stride_w = cc_stride_w; a.wc = wc; a.wt = wt; a.mar = d_mar; a.frac = d_frac; a.xlogx = d_xlogx;
-    a.a_begin = a_begin; a.n_a = n_a; a.b_begin = b_begin; a.n_b = n_b;
-    a.n_individs = (int)n_individs; a.threshold = threshold;
-    a.hits = d_hits; a.max_hits = max_hits; a.tally = d_tally; a.dense = d_dense;
-    a.marf = d_marf; a.bound_threshold = bound_threshold; a.dense_err = dense_err ? 1 : 0;
-    a.cct = d_cct;
-    a.ticket = nullptr; a.first_gen = 0; a.stagger_ticks = 0;
-    a.lg_n = (float)(std::log2((double)(n_individs ? n_individs : 1u)) * 1.000001) + 1.0e-5f;
-    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const bool pre = prefilter && d_marf;
-    const bool small_case_group = wc * 32u < 65536u && !both_groups;  // case counts fit uint16
+    a.cc = l.d_cc; a.cc_stride_w = l.cc_stride_w; a.wc = l.wc; a.wt = l.wt; a.mar = l.d_mar; a.frac = l.d_frac; a.xlogx = l.d_xlogx;
+    a.a_begin = l.a_begin; a.n_a = l.n_a; a.b_begin = l.b_begin; a.n_b = l.n_b;
+    a.n_individs = (int)l.n_individs; a.threshold = l.threshold;
+    a.hits = l.d_hits; a.max_hits = l.max_hits; a.tally = l.d_tally; a.dense = l.d_dense;
+    a.marf = l.d_marf; a.bound_threshold = l.bound_threshold; a.dense_err = l.dense_err ? 1 : 0;
+    a.cct = l.matrix_cores ? l.d_cct : nullptr;
+    a.lg_n = (float)(std::log2((double)(l.n_individs ? l.n_individs : 1u)) * 1.000001) + 1.0e-5f;
+    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    a.fp4_scale[0] = 126; a.fp4_scale[1] = 127; a.fp4_scale[2] = 128;
+    a.cand = l.candidates.records; a.cand_count = l.candidates.count; a.cand_cap = l.candidates.capacity;
+    const bool fast = l.no_missing_call;
+    const bool pre = l.prefilter && l.d_marf;
+    const bool exact_in_f32 = l.n_individs < (1u << 24);  // the FP4 kernels count in FP32 accumulators
+    const bool small_case_group = l.wc * 32u < 65536u && l.matrix_cores != 2;  // case counts fit uint16
     // the instantiation the launch goes to, spelled as rocprofv3's kernel trace prints it (gw_last_boost_kernel)
     auto note = [&](const char *fmt, const char *x, const char *y) {
-        if (kernel_name) std::snprintf(kernel_name, 96, fmt, x, y);
+        if (l.kernel_name) std::snprintf(l.kernel_name, 96, fmt, x, y, l.d_dense ? "true" : "false");
     };
     const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
-    a.klogk = d_klogk; a.park = d_park;
-    a.fp4_scale[0] = 126; a.fp4_scale[1] = 127; a.fp4_scale[2] = 128;
-    // small cohorts without a missing call: the persistent kernel with the bound's logarithms in an LDS table
-    if (d_cct && d_marf && small_case_group && fast && pre && !d_dense && d_klogk && d_park && n_individs <= 16383u) {
-        if (d_ticket && stagger_ticks) {  // one ticket counter per CU (4096 keys)
-            hipError_t e = hipMemsetAsync(d_ticket, 0, 4096 * sizeof(unsigned int), stream);
-            if (e != hipSuccess) return e;
-            a.ticket = d_ticket; a.stagger_ticks = stagger_ticks;
-        }
-        note("gw::k_boost_mfma_lut%s", "", "");
-        return launch_boost_mfma_lut4(a, compute_units, stream);
-    }
-    // the pair tables counted on FP4 operands (8 samples per operand dword, 64 per MFMA): four corners / nine cells
-    if (d_cct && d_marf && small_case_group && fp4) {
-        // the first level pays while it stops nearly every pair: it is loose by ~0.4 x a chi^2 with 8 degrees of freedom, so
-        // below a threshold of ~25 more than one wave in five would run both levels (diagnostic form: whenever asked)
-        if (fast && pre && first_level && (threshold >= 25.0 || d_dense)) a.quad = quad_bound_constants(n_cases, n_individs);
-        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2, %s>" : "gw::k_boost_mfma_fp4<%s, 3, 1, %s>", tp,
+    // the first level pays while it stops nearly every pair: it is loose by ~0.4 x a chi^2 with 8 degrees of freedom, so
+    // below a threshold of ~25 more than one wave in five would run both levels (diagnostic form: whenever asked)
+    const bool first = fast && pre && l.first_level && (l.threshold >= 25.0 || l.d_dense);
+    // the pair tables counted on FP4 operands (8 samples per operand dword, 64 per MFMA): four corners / nine cells,
+    // one group at a time with the case counts parked in LDS as uint16
+    if (a.cct && l.d_marf && small_case_group && l.fp4 && exact_in_f32) {
+        if (first) a.quad = quad_bound_constants(l.n_cases, l.n_individs);
+        note(fast ? "gw::k_boost_mfma_fp4<%s, 2, 2, %s, %s>" : "gw::k_boost_mfma_fp4<%s, 3, 1, %s, %s>", tp,
              a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
-        return launch_boost_mfma_fp4(a, pre, !fast, stream);
+        return launch_boost_mfma_fp4(a, pre, !fast, l.compute_units, l.stream);
     }
-    if (d_cct && d_marf && small_case_group) {  // one group at a time: 4 corners on 64 x 32 pairs per wave, or 9 cells
-        if (d_ticket && stagger_ticks && !d_dense) {
-            hipError_t e = hipMemsetAsync(d_ticket, 0, sizeof(unsigned int), stream);
-            if (e != hipSuccess) return e;
-            a.ticket = d_ticket; a.first_gen = first_gen; a.stagger_ticks = stagger_ticks;
-        }
+    if (a.cct && l.d_marf && small_case_group) {  // the same on int8 operands (exact in int32 for any cohort)
         note(fast ? "gw::k_boost_mfma_seq<%s, 2, 2, false>" : "gw::k_boost_mfma_seq<%s, 3, 1, false>", tp, "");
-        return fast ? launch_boost_mfma_seq4(a, pre, stream) : launch_boost_mfma_seq9(a, pre, stream);
+        return fast ? launch_boost_mfma_seq4(a, pre, l.stream) : launch_boost_mfma_seq9(a, pre, l.stream);
     }
     // tables without a missing call, case groups of any size: the FP4 kernel with both groups' accumulators in registers
-    // (the counts are exact in FP32 below 2^24)
-    if (d_cct && d_marf && fast && fp4 && n_individs < (1u << 24)) {
-        if (pre && first_level && (threshold >= 25.0 || d_dense)) a.quad = quad_bound_constants(n_cases, n_individs);
-        note("gw::k_boost_mfma_fp4_both<%s, %s>", tp, a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
-        return launch_boost_mfma_fp4_both(a, pre, stream);
+    if (a.cct && l.d_marf && fast && l.fp4 && exact_in_f32) {
+        if (first) a.quad = quad_bound_constants(l.n_cases, l.n_individs);
+        note("gw::k_boost_mfma_fp4_both<%s, %s, %s>", tp, a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
+        return launch_boost_mfma_fp4_both(a, pre, l.compute_units, l.stream);
     }
-    if (d_cct && fast) {  // any group size, 2 waves per SIMD
+    if (a.cct && fast) {  // any group size, 2 waves per SIMD
         note("gw::k_boost_mfma<%s>", tp, "");
-        return launch_boost_mfma_both4(a, pre, stream);
+        return launch_boost_mfma_both4(a, pre, l.stream);
     }
-    if (d_cct && d_marf) {  // any group size, 1 wave per SIMD
+    if (a.cct && l.d_marf) {  // any group size, 1 wave per SIMD
         note("gw::k_boost_mfma_seq<%s, 3, 1, true>", tp, "");
-        return launch_boost_mfma_both9(a, pre, stream);
+        return launch_boost_mfma_both9(a, pre, l.stream);
     }
     note("gw::k_boost<%s, %s>", tfast, tp);
-    return launch_boost_valu(a, fast, pre, stream);
+    return launch_boost_valu(a, fast, pre, l.stream);
 }
 
 }  // namespace gw

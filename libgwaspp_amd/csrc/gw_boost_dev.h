@@ -1,6 +1,6 @@
 // gw_boost_dev.h -- device-side pieces shared by the pair-path translation units
-// (gw_boost.hip, gw_boost_mfma.hip, gw_boost_seq4.hip, gw_boost_seq9.hip, gw_boost_both9.hip; split so that they compile in
-// parallel: the unrolled per-pair epilogues make each of them a minute of compile time).
+// (gw_boost.hip, gw_boost_mfma.hip, gw_boost_seq4.hip, gw_boost_seq9.hip, gw_boost_both9.hip, gw_boost_fp4*.hip; split so that
+// they compile in parallel: the unrolled per-pair epilogues make each of them a minute of compile time).
 #pragma once
 #include <type_traits>
 
@@ -8,6 +8,10 @@
 
 namespace gw {
 
+
+// v_mul_legacy_f32 (0 * anything = 0, also 0 * inf): clang has no builtin for it, the LLVM intrinsic is reached by name --
+// as a real instruction to the compiler (scheduled, hazards handled), unlike an inline-asm statement
+extern "C" __device__ float gw_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
 
 // compile-time loop: the body sees its index as a constant
 template <int I, int N, typename F>
@@ -155,7 +159,7 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
     err = 5.9604645e-8f * (n * (8.5f * lg_n + 69.0f + 7.2f * fabsf(lt)) + 6.0f * fabsf(r));
     return r;
 }
-// A FIRST-level bound without the 27 logarithms, for the same tables (no missing call).  With h the binary entropy in
+// A FIRST-level bound without any logarithm, for the same tables (no missing call).  With h the binary entropy in
 // bits, A = sum_cells (x lg x + y lg y - s lg s) = - sum_cells s h(x / s).  For an expansion point p (the cases'
 // share of the cohort, as a float) the two-piece quadratic
 //   h(p) + h'(p)(z - p) - c(z) (z - p)^2,   c(z) = c_lo for z < p, c_hi for z > p
@@ -165,24 +169,44 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
 // largest at an end of that side), and because the x of a table add up to the case count,
 //   A <= k0 + sum_cells c(x / s) (x - p s)^2 / s,   k0 = -n h(p) - h'(p)(n_case - p n).
 // With d = x - p s, c_m = (c_lo + c_hi) / 2 and c_d = (c_hi - c_lo) / 2 the sum is c_m sum d^2 / s + c_d sum d |d| / s:
-// nine v_rcp_f32 instead of 27 v_log_f32, about 60 % of the vector issue slots of boost_bound_split.  The rest of the
-// measure (K_i + K_j + n lg tao) is kept as it is.  The bound is one-sided, measure <= bound1 + err1, and loose by
+// nine v_rcp_f32 instead of 27 v_log_f32.  The bound is one-sided, measure <= bound1 + err1, and loose by
 // (2 c ln 2 p (1 - p) - 1) times a cell's share of the pair's saturated-model G statistic -- 0.39 x a chi^2 with 8
 // degrees of freedom for a balanced cohort, where c_lo ~ c_hi ~ 4; for a lopsided one the factor is 0 on the long
 // side of p and at most 1 on the short one.  On the bench's input 3.4 pairs in 10 000 reach a threshold of 30
-// (tools/bound_study.py) and go on to boost_bound_split.  The constants are exact by definition (the host rounds
-// c_lo, c_hi and k0 up), so only the arithmetic rounds; with c = max(c_lo, c_hi) = c_m + |c_d| and q = sum d^2 / s:
-//   * d = fma(-p, s, x): u |d|; 1 / max(s, 1): 2u; t = d / s: 4u relative; q_m = fma(d, t, q_m), q_d = fma(|d|, t, q_d):
-//     5u of the term + u q per step, nine steps: 14u q each;  A1 = fma(c_d, q_d, fma(c_m, q_m, k0)):
-//     14u c q + 2u (c q + |k0|),  |k0| <= 1.01 n:                                                  u (16 c q + 2.02 n)
-//   * K_i, K_j rounded (2.07 n u), (A1 + K_i) + K_j: u (2 |A1| + 2 |K_i| + |K_j|):                   u (2 c q + 7.2 n)
-//   * tao and n lt, the final sum as in boost_bound_split:                 23 u n + 5.02 u n |L| + u |final|
-//   => times 2 ln 2 and the factor's roundings:  u [ 25 c q + 44.8 n + 6.96 n |L| + 3.5 |bound| ];
-//   err below uses (27, 48, 7.2, 6).  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
-//   measure (check_upper_bound), as it checks the second level.
+// (tools/bound_study.py) and go on to boost_bound_split.
+//
+// Round 4: the rest of the measure, K_i + K_j + n lg tao, without its logarithm and with a third of its multiply-adds.
+//   * lg tao <= lg e (tao - 1) for every tao > 0, so  n lg tao <= N1 (tao - 1), N1 = n lg e: still an upper bound.  On
+//     unlinked SNPs |tao - 1| < 1e-4 and the slack n (tao - 1 - ln tao) is below 1e-4 (tools/bound_study.py).
+//   * tao - 1 from the four corners.  tao = sum_abc p(ab) p(ac) p(bc) / (p(a) p(b) p(c)) (epistasis_func.cpp:424-470; a, b the
+//     genotypes of the two SNPs, c the status).  With d_ac = P(c | a) / P(c) - 1 for the first SNP and e_bc likewise for
+//     the second, P(c | a) / P(c) = 1 + d_ac, sum_c P(c) d_ac = 0 = sum_c P(c) e_bc (every individual is a case or a
+//     control) and sum_ab p(ab) = 1 (no missing call):
+//         tao - 1 = sum_c P(c) sum_ab p(ab) d_ac e_bc = sum_c sum_ab S_ab u_a v_b,   u_a = d_ac, v_b = P(c) e_bc / n, S = s counts.
+//     The rows and columns of S add up to the SNPs' own genotype counts R_a, C_b, with sum_a R_a u_a = 0 = sum_b C_b v_b, so
+//     writing u_a = u_1 + u'_a, v_b = v_1 + v'_b (u'_1 = v'_1 = 0) leaves
+//         sum_ab S_ab u_a v_b = sum_{a, b in {0, 2}} S_ab u'_a v'_b - n u_1 v_1
+//     -- four products per group on the CORNER totals the kernel has anyway, and the result is tao - 1 itself (magnitude
+//     1e-5) instead of tao (magnitude 1), so nothing cancels against the 1: 14 instead of 24 multiply-adds per pair.
+//     u'_a, n u_1 (SnpMarginF::ua) and v'_b, v_1 (::vb) are per-SNP numbers computed in FP64 by k_margins.
+//
+// The constants are exact by definition (the host rounds c_lo, c_hi and k0 up), so only the arithmetic rounds; with
+// c = max(c_lo, c_hi) = c_m + |c_d| and q = sum d^2 / s (u = 2^-24):
+//   * d = fma(-p, s, x): u |d|; 1 / s: 2u (v_rcp_f32, 1 ulp; s == 0 has d == 0 and v_mul_legacy_f32 makes 0 x inf = 0);
+//     t = d / s: 4u relative; q_m = fma(d, t, q_m), q_d = fma(|d|, t, q_d): 5u of the term + u q per step, nine steps: 14u q
+//     each;  A1 = fma(c_d, q_d, fma(c_m, q_m, k0)): 14u c q + 2u (c q + |k0|),  |k0| <= 1.01 n:          u (16 c q + 2.02 n)
+//   * K_i, K_j rounded (2.07 n u), (A1 + K_i) + K_j: u (2 |A1| + 2 |K_i| + |K_j|):                       u (2 c q + 7.2 n)
+//   * tao - 1: every term S u' v' (S exact) carries 2u from its rounded factors and <= 3u from the multiply-adds it passes
+//     through, so the computed sum is within 6u T of the exact one, T = the sum of the terms' magnitudes, and
+//     T <= sum_c [max_a |u'_a| sum_b C_b |v'_b| + n |u_1| |v_1|] <= ea_i eb_j (SnpMarginF::ea, ::eb, rounded up).  Times N1
+//     (rounded: u) and with |tao - 1| <= T:  N1 (tao - 1) is within 8u N1 T = 11.6 u n T.
+//   * the final sum and the factor 2 ln 2 with its roundings:  u (25 c q + 13 n + 16.1 n T) + 3.5 u |bound|
+//   err below uses (27, 48, 30, 6).  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
+//   measure (check_upper_bound in k_boost_finish), as it checks the second level.
 struct QuadBound {
     float p, c_m, c_d, k0, c27;  // c27 = 27 max(c_lo, c_hi); c_m == 0: no first level
-    float n48, n72;              // 48 n and 7.2 n (rounded up): the error bound as three multiply-adds
+    float n48, n30;              // 48 n and 30 n (rounded up): the error bound's constant terms
+    float n1;                    // N1 = n lg e
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
 // TWO = false: one curvature constant for both sides (the host sets c_m = max(c_lo, c_hi), c_d = 0 -- what a balanced
@@ -191,30 +215,32 @@ template <bool TWO = true>
 __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const float (&fs)[9],
                                                     const SnpMarginF &f1, const SnpMarginF &f2, float n,
                                                     const QuadBound &qb, float &err) {
-    float q_m = 0.0f, q_d = 0.0f, tao = 0.0f;
+    float q_m = 0.0f, q_d = 0.0f;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float in_c = 0.0f, in_t = 0.0f;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const float x = fx[3 * a + b], s = fs[3 * a + b];
-            const float d = __builtin_fmaf(-qb.p, s, x);
-            const float t = d * __builtin_amdgcn_rcpf(fmaxf(s, 1.0f));  // s == 0: d == 0
-            q_m = __builtin_fmaf(d, t, q_m);
-            if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
-            in_c = __builtin_fmaf(s, f2.rb[b], in_c);
-            in_t = __builtin_fmaf(s, f2.rb[3 + b], in_t);
-        }
-        tao = __builtin_fmaf(f1.pa[a], in_c, tao);
-        tao = __builtin_fmaf(f1.pa[3 + a], in_t, tao);
+    for (int c = 0; c < 9; ++c) {
+        const float x = fx[c], s = fs[c];
+        const float d = __builtin_fmaf(-qb.p, s, x);
+        const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
+        q_m = __builtin_fmaf(d, t, q_m);
+        if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
     }
-    const float lt = __log2f(tao);
+    // tao - 1 = sum over the groups of  u'_0 (v'_0 S00 + v'_2 S02) + u'_2 (v'_0 S20 + v'_2 S22) - (n u_1) v_1
+    float t1 = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float r0 = __builtin_fmaf(f2.vb[3 * g + 1], fs[2], f2.vb[3 * g] * fs[0]);
+        const float r2 = __builtin_fmaf(f2.vb[3 * g + 1], fs[8], f2.vb[3 * g] * fs[6]);
+        t1 = __builtin_fmaf(f1.ua[3 * g], r0, t1);
+        t1 = __builtin_fmaf(f1.ua[3 * g + 1], r2, t1);
+        t1 = __builtin_fmaf(-f1.ua[3 * g + 2], f2.vb[3 * g + 2], t1);
+    }
     const float A0 = __builtin_fmaf(qb.c_m, q_m, qb.k0);
     const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
-    const float r = 1.3862943611198906f * (((A1 + f1.ki) + f2.kj) + n * lt);  // 2 ln 2
-    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(6.0f, fabsf(r), __builtin_fmaf(qb.n72, fabsf(lt), qb.n48)));
+    const float r = 1.3862943611198906f * __builtin_fmaf(qb.n1, t1, (A1 + f1.ki) + f2.kj);  // 2 ln 2
+    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(6.0f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48)));
     return r;
 }
+template <bool TWO = true>
 __device__ __forceinline__ float boost_bound_quad(const uint32_t (&ca)[9], const uint32_t (&co)[9],
                                                   const SnpMarginF &f1, const SnpMarginF &f2, float n,
                                                   const QuadBound &qb, float &err) {
@@ -224,7 +250,7 @@ __device__ __forceinline__ float boost_bound_quad(const uint32_t (&ca)[9], const
         fx[c] = (float)ca[c];
         fs[c] = (float)(ca[c] + co[c]);
     }
-    return boost_bound_quad_f(fx, fs, f1, f2, n, qb, err);
+    return boost_bound_quad_f<TWO>(fx, fs, f1, f2, n, qb, err);
 }
 // true: the pair is provably below the threshold (NaN / Inf anywhere -> false -> FP64 decides)
 __device__ __forceinline__ bool bound_rules_out(float bound, float err, float bound_threshold) {
@@ -237,6 +263,32 @@ __device__ __forceinline__ void check_bound(double measure, float bound, float e
 // ... and of the one-sided first level
 __device__ __forceinline__ void check_upper_bound(double measure, float bound, float err, unsigned long long *tally) {
     if (measure > (double)bound + (double)err) atomicAdd(&tally[2], 1ull);  // false for NaN
+}
+
+// The two 3 x 3 tables of a pair from its counted cells (cells[0] cases, [1] controls).  NV = 3: all nine cells counted;
+// NV = 2 (tables without a missing call): the four corners aa/aa, aa/bb, bb/aa, bb/bb counted, the rest from the SNPs' own
+// genotype counts f1 (first marker) and f2 (table5.cpp:1088-1106 / 1125-1143)
+template <int NV>
+__device__ __forceinline__ void boost_tables_of(const uint32_t (&cells)[2][NV * NV], const uint32_t *f1c, const uint32_t *f1t,
+                                                const uint32_t *f2c, const uint32_t *f2t, uint32_t (&ca)[9], uint32_t (&co)[9]) {
+    constexpr int NP = NV * NV;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        uint32_t *o = g == 0 ? ca : co;
+        if (NV == 3) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) o[c] = cells[g][c % NP];
+        } else {
+            const uint32_t *f1 = g == 0 ? f1c : f1t;
+            const uint32_t *f2 = g == 0 ? f2c : f2t;
+            o[0] = cells[g][0]; o[2] = cells[g][1]; o[6] = cells[g][2 % NP]; o[8] = cells[g][3 % NP];
+            o[1] = f1[0] - o[0] - o[2];
+            o[7] = f1[2] - o[8] - o[6];
+            o[3] = f2[0] - o[0] - o[6];
+            o[5] = f2[2] - o[2] - o[8];
+            o[4] = f2[1] - o[1] - o[7];
+        }
+    }
 }
 
 struct BoostArgs {
@@ -259,34 +311,24 @@ struct BoostArgs {
     float lg_n;                 // PRE: log2(n_individs), rounded up (boost_bound_split's error bound)
     QuadBound quad;             // PRE, tables without a missing call: the first-level bound's constants (c_m == 0: none)
     int fp4_scale[3];           // k_boost_mfma_fp4: E8M0 block scales 2^-1, 2^0, 2^1 (126, 127, 128), as run-time values
-    const float *klogk;         // k_boost_mfma_lut: k log2 k, k = 0 .. n_individs
-    uint32_t *park;             // k_boost_mfma_lut: 64 KB per resident workgroup for the parked case counts
-    // Start-up stagger of the one-group-at-a-time MFMA kernels: a workgroup's life is a matrix-core phase (counting)
-    // followed by a vector-ALU phase (the per-pair bound / measure), and the two workgroups a CU holds start
-    // together and stay in step -- both count, then both evaluate, the matrix cores idle meanwhile.  The
-    // workgroups of the first generation (ticket < first_gen) that sit in an odd wave slot wait stagger_ticks of
-    // the 100 MHz clock before they start, once; from then on one workgroup's evaluation runs under the
-    // other's counting.  ticket: a device counter zeroed before the launch; null / 0 = no stagger.
-    unsigned int *ticket;
-    uint32_t first_gen, stagger_ticks;
+    // PRE, the FP4 kernels: the pairs the in-kernel bound could not rule out go to this list (gw_kernels.h
+    // BoostCandidateList) and get their second level / FP64 measure from k_boost_finish
+    uint32_t *cand;
+    unsigned long long *cand_count;
+    unsigned long long cand_cap;
 };
 
-// (see BoostArgs::ticket) called by every thread of a workgroup that has work, before it starts
-__device__ __forceinline__ void boost_stagger(const BoostArgs &a, uint32_t *s_flag) {
-    if (!a.ticket || !a.stagger_ticks) return;
-    if (threadIdx.x == 0) {
-        const uint32_t tk = atomicAdd(a.ticket, 1u);
-        uint32_t hw_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        *s_flag = (tk < a.first_gen && (hw_id & 1u)) ? 1u : 0u;   // HW_ID[3:0] = the wave's slot on its SIMD
-    }
-    __syncthreads();
-    if (*s_flag) {
-        const uint64_t t0 = wall_clock64();
-        while (wall_clock64() - t0 < (uint64_t)a.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+// a pair over the threshold (epistasis_func.cpp:482-484): appended while the list has room, counted either way
+__device__ __forceinline__ void boost_append_hit(const BoostArgs &a, uint32_t i, uint32_t j, double measure) {
+    const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
+    if (slot < a.max_hits) {
+        BoostHit h;
+        h.snp_a = i;
+        h.snp_b = j;
+        h.measure = measure;
+        a.hits[slot] = h;
     }
 }
-
 
 // ---- operand expansion of the int8 MFMA kernels
 constexpr int MT = 64;  // SNPs per workgroup tile side
@@ -323,8 +365,11 @@ hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t str
 hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq4.hip
 hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
 hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
-hipError_t launch_boost_mfma_lut4(const BoostArgs &a, int compute_units, hipStream_t stream);     // gw_boost_lut4.hip
-hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, hipStream_t stream);    // gw_boost_fp4.hip
-hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, hipStream_t stream);          // gw_boost_fp4.hip
+// (the FP4 launchers enqueue k_boost_finish behind the screen when it is one with a pre-filter: compute_units sizes its grid)
+hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, int compute_units, hipStream_t stream);  // gw_boost_fp4*.hip
+hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);
+// every pair in FP64 (pre = false) and the forms with a value per pair (a.dense): gw_boost_fp4_full.hip
+hipError_t launch_boost_mfma_fp4_full(const BoostArgs &a, bool pre, bool nine, hipStream_t stream);
+hipError_t launch_boost_mfma_fp4_both_full(const BoostArgs &a, bool pre, hipStream_t stream);
 
 }  // namespace gw

@@ -79,8 +79,6 @@ struct gw_table {
     uint32_t wc = 0, wt = 0;
     gw::SnpMargin *d_mar = nullptr;
     gw::SnpMarginF *d_marf = nullptr;
-    float *d_klogk = nullptr;    // k log2 k, k = 0 .. sel_individs (k_boost_mfma_lut; cohorts of at most 16 383)
-    uint32_t *d_park = nullptr;  // ... and 64 KB per resident workgroup for its parked case counts
     gw::u32x4 *d_cct = nullptr;  // block-tiled copy of d_cc for the MFMA pair kernel (tables without missing calls)
     double *d_frac = nullptr, *d_xlogx = nullptr;  // k/n and (k/n) log(k/n), k = 0..n
     bool selected_valid = false, any_missing = true;
@@ -92,6 +90,8 @@ struct gw_table {
     size_t hits_buf_bytes = 0;
     double *d_dense_buf = nullptr;
     size_t dense_buf_bytes = 0;
+    uint32_t *d_cand = nullptr;    // the pair screen's candidate records (gw_kernels.h BoostCandidateList), grow-only
+    size_t cand_bytes = 0;
 
     // rows packed by gw_table_add_genotype_row, waiting for the next flush
     std::vector<uint16_t> pending;
@@ -99,7 +99,8 @@ struct gw_table {
     uint32_t pending_rows = 0, pending_cap = 0;
 
     // kernel shape
-    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_stagger = -1, opt_boost_lut = 0, opt_boost_fp4 = 1, opt_boost_first_level = 1;
+    int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_fp4 = 1, opt_boost_first_level = 1;
+    long long opt_boost_candidates = 0;  // records the candidate list may hold; 0 = auto (from the size of the block pair)
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -401,8 +402,7 @@ int gw_table_destroy(gw_table *t) {
     if (t->d_raw) (void)hipFree(t->d_raw);
     if (t->d_frac) (void)hipFree(t->d_frac);
     if (t->d_xlogx) (void)hipFree(t->d_xlogx);
-    if (t->d_klogk) (void)hipFree(t->d_klogk);
-    if (t->d_park) (void)hipFree(t->d_park);
+    if (t->d_cand) (void)hipFree(t->d_cand);
     if (t->d_tally) (void)hipFree(t->d_tally);
     if (t->d_hits_buf) (void)hipFree(t->d_hits_buf);
     if (t->d_dense_buf) (void)hipFree(t->d_dense_buf);
@@ -889,8 +889,8 @@ int ensure_selected(gw_table *t) {
         if (t->d_cc) { GW_HIP(hipFree(t->d_cc)); t->d_cc = nullptr; }
         if (t->d_cct) { GW_HIP(hipFree(t->d_cct)); t->d_cct = nullptr; }
     }
-    // [0..3] the kernels' tally, [4..] 4096 uint32 ticket counters (start-up stagger of the pair kernels)
-    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 4 * sizeof(unsigned long long) + 4096 * sizeof(unsigned int)));
+    // [0..3] the kernels' tally, [4] the candidate counter of the pair screen
+    if (!t->d_tally) GW_HIP(hipMalloc((void **)&t->d_tally, 8 * sizeof(unsigned long long)));
     if (m) {
         if (!t->d_cc) GW_HIP(hipMalloc((void **)&t->d_cc, m * stride_w * sizeof(uint32_t)));
         if (!t->d_mar) GW_HIP(hipMalloc((void **)&t->d_mar, m * sizeof(gw::SnpMargin)));
@@ -940,16 +940,11 @@ int ensure_selected(gw_table *t) {
     if (!t->d_frac || individs != t->sel_individs) {  // the k/n and (k/n) log(k/n) tables depend on n only
         if (t->d_frac) { GW_HIP(hipFree(t->d_frac)); t->d_frac = nullptr; }
         if (t->d_xlogx) { GW_HIP(hipFree(t->d_xlogx)); t->d_xlogx = nullptr; }
-        if (t->d_klogk) { GW_HIP(hipFree(t->d_klogk)); t->d_klogk = nullptr; }
         GW_HIP(hipMalloc((void **)&t->d_frac, ((size_t)individs + 1u) * sizeof(double)));
         GW_HIP(hipMalloc((void **)&t->d_xlogx, ((size_t)individs + 1u) * sizeof(double)));
-        if (individs <= 16383u)  // k_boost_mfma_lut: k log2 k, and the parking space of its resident workgroups
-            GW_HIP(hipMalloc((void **)&t->d_klogk, ((size_t)individs + 1u) * sizeof(float)));
     }
-    if (t->d_klogk && !t->d_park) GW_HIP(hipMalloc((void **)&t->d_park, gw::boost_lut_park_bytes(t->compute_units)));
     t->sel_individs = individs;
     t->sel_cases = (uint32_t)cases.size();
-    if (t->d_klogk) GW_HIP(gw::launch_boost_klogk(t->sel_individs + 1u, t->d_klogk, t->stream));
     GW_HIP(gw::launch_boost_tables(t->sel_individs + 1u, t->sel_individs, t->d_frac, t->d_xlogx, t->stream));
     GW_HIP(hipStreamSynchronize(t->stream));
     t->any_missing = false;
@@ -973,11 +968,45 @@ double from_ordered(unsigned long long u) {
     return d;
 }
 
-// GW_OPT_BOOST_STAGGER_US: -1 auto, 0 off, > 0 microseconds
-uint32_t boost_stagger_ticks(const gw_table *t) {
-    if (t->opt_boost_stagger == 0) return 0;
-    if (t->opt_boost_stagger > 0) return (uint32_t)t->opt_boost_stagger * 100u;
-    return 0;  // auto: decided after measurement
+// should this block pair go through the FP32 bound first?  One predicate for every form of the screen (host list, device
+// list, list header): the bound's error model takes float(count) to be exact, so cohorts of 2^24 members or more get every
+// pair in FP64
+bool boost_prefilter_on(const gw_table *t) { return t->opt_prefilter != 0 && t->sel_individs < (1u << 24); }
+
+// the candidate list of a screen over `pairs_upper` pairs at most: grow-only, owned by the handle.  Auto size: one
+// record per 64 pairs + 65 536 but at least 2^20, at most one per pair and 32 M records (the logarithm-free first level lets ~3 pairs in 10 000 through
+// on unlinked SNPs; a block that overflows it is repeated with every pair in FP64, so the size only bounds the cost)
+int boost_candidates(gw_table *t, unsigned long long pairs_upper, gw::BoostCandidateList *out) {
+    const size_t rec = gw::boost_candidate_bytes(t->any_missing);
+    // (a block pair of up to 2^20 pairs gets a record per pair: whatever the threshold, it cannot overflow)
+    unsigned long long want = t->opt_boost_candidates > 0
+                                  ? (unsigned long long)t->opt_boost_candidates
+                                  : std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper / 64u + 65536u, 1ull << 20),
+                                                                 std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper, 1ull), 32ull << 20));
+    const size_t need = (size_t)want * rec;
+    if (need > t->cand_bytes) {
+        if (t->d_cand) GW_HIP(hipFree(t->d_cand));
+        t->d_cand = nullptr;
+        t->cand_bytes = 0;
+        GW_HIP(hipMalloc((void **)&t->d_cand, need));
+        t->cand_bytes = need;
+    }
+    out->records = t->d_cand;
+    out->count = t->d_tally + 4;
+    out->capacity = want;
+    return GW_OK;
+}
+
+// everything about a launch that comes from the handle (ensure_selected has run)
+void boost_launch_of(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
+                     hipStream_t stream, gw::BoostLaunch &l) {
+    l.d_cc = t->d_cc; l.cc_stride_w = t->cc_stride_w; l.wc = t->wc; l.wt = t->wt; l.d_cct = t->d_cct;
+    l.d_mar = t->d_mar; l.d_marf = t->d_marf; l.d_frac = t->d_frac; l.d_xlogx = t->d_xlogx;
+    l.n_individs = t->sel_individs; l.n_cases = t->sel_cases; l.no_missing_call = !t->any_missing;
+    l.a_begin = (uint32_t)a_begin; l.n_a = (uint32_t)n_a; l.b_begin = (uint32_t)b_begin; l.n_b = (uint32_t)n_b;
+    l.threshold = threshold;
+    l.matrix_cores = t->opt_boost_mfma; l.fp4 = t->opt_boost_fp4 != 0; l.compute_units = t->compute_units;
+    l.stream = stream; l.kernel_name = t->last_boost_kernel;
 }
 
 int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b, double threshold,
@@ -1025,21 +1054,22 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     // Options 2 / 3 = diagnostic: the dense form returns the bound / its error bound instead of the measure.
     // (the bound's error model takes float(count) to be exact: cohorts of 2^24 members or more get every pair in FP64)
     const bool diag = dense && t->opt_prefilter >= 2;
-    const bool pre = diag || (!dense && !vmax && !vmin && t->opt_prefilter != 0 && t->sel_individs < (1u << 24));
+    const bool pre = diag || (!dense && !vmax && !vmin && boost_prefilter_on(t));
     float bound_thr = 0.0f;
     if (pre && !diag) {
         bound_thr = (float)threshold;
         if (!((double)bound_thr <= threshold)) bound_thr = std::nextafter(bound_thr, -INFINITY);  // round down; NaN stays NaN
     }
+    gw::BoostLaunch l;
+    boost_launch_of(t, a_begin, n_a, b_begin, n_b, threshold, t->stream, l);
+    l.d_hits = d_hits; l.max_hits = max_hits; l.d_tally = t->d_tally; l.d_dense = d_dense;
+    l.bound_threshold = bound_thr;
+    l.dense_err = t->opt_prefilter == 3 || t->opt_prefilter == 5;
+    l.first_level = diag ? t->opt_prefilter >= 4 : t->opt_boost_first_level != 0;
+    if (pre && !dense && (rc = boost_candidates(t, (unsigned long long)n_a * n_b, &l.candidates))) return rc;
     auto launch = [&](bool prefilter) {
-        return gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
-                                (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, max_hits,
-                                t->d_tally, d_dense, !t->any_missing, t->stream, t->d_marf, prefilter, bound_thr,
-                                t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, t->opt_prefilter == 3 || t->opt_prefilter == 5,
-                                t->last_boost_kernel, reinterpret_cast<unsigned int *>(t->d_tally + 4),
-                                (uint32_t)t->compute_units * 2u, boost_stagger_ticks(t),
-                                t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0,
-                                t->sel_cases, diag ? t->opt_prefilter >= 4 : t->opt_boost_first_level != 0);
+        l.prefilter = prefilter;
+        return gw::launch_boost(l);
     };
     if (e == hipSuccess) e = launch(pre);
     unsigned long long tally[4] = {0, 0, 0, ~0ull};
@@ -1072,6 +1102,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     // large call (a dense block of 20 k x 20 k measures is 3.2 GB) must not sit next to a 125 GB table for ever
     const size_t keep = (size_t)256u << 20;
     if (t->dense_buf_bytes > keep) { (void)hipFree(t->d_dense_buf); t->d_dense_buf = nullptr; t->dense_buf_bytes = 0; }
+    if (t->cand_bytes > keep) { (void)hipFree(t->d_cand); t->d_cand = nullptr; t->cand_bytes = 0; }
     if (t->hits_buf_bytes > keep) { (void)hipFree(t->d_hits_buf); t->d_hits_buf = nullptr; t->hits_buf_bytes = 0; }
     return GW_OK;
 }
@@ -1094,7 +1125,10 @@ int gw_boost_list_init(gw_table *t, void *d_list, void *hip_stream) {
     if (rc) return rc;
     // the kernels' tally: hits, pairs, then (pre-filter on) pairs outside the bound's error model / unused,
     // or (pre-filter off) the ordered maximum / minimum of the measures
-    const bool pre = t->opt_prefilter != 0;
+    // (the same predicate as the screen itself: with a cohort of 2^24 or more the screen runs without the pre-filter and
+    // slots 2 / 3 are the extremes; the cohort is known once the masks are set, which a screen needs anyway)
+    if ((rc = ensure_selected(t))) return rc;
+    const bool pre = boost_prefilter_on(t);
     const unsigned long long init[4] = {0ull, 0ull, 0ull, pre ? 0ull : ~0ull};
     GW_HIP(hipMemcpyAsync(d_list, init, sizeof init, hipMemcpyHostToDevice, pick_stream(t, hip_stream)));
     GW_HIP(hipStreamSynchronize(pick_stream(t, hip_stream)));  // `init` lives on this stack
@@ -1111,21 +1145,20 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
     if (t->tv.n_snps > 0xFFFFFFFFull) return fail(GW_E_RANGE, "pair analysis supports up to 2^32-1 SNPs");
     if ((rc = ensure_selected(t))) return rc;  // compaction + margins, once per mask / data change (synchronous)
     if ((rc = use_device(t))) return rc;
-    const bool pre = t->opt_prefilter != 0 && t->sel_individs < (1u << 24);  // as in the host form
+    const bool pre = boost_prefilter_on(t);  // as in the host form and in gw_boost_list_init
     float bound_thr = 0.0f;
     if (pre) {
         bound_thr = (float)threshold;
         if (!((double)bound_thr <= threshold)) bound_thr = std::nextafter(bound_thr, -INFINITY);
     }
-    unsigned long long *tally = static_cast<unsigned long long *>(d_list);
-    gw::BoostHit *d_hits = reinterpret_cast<gw::BoostHit *>(static_cast<char *>(d_list) + GW_BOOST_LIST_HEADER_BYTES);
-    GW_HIP(gw::launch_boost(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->d_frac, t->d_xlogx, (uint32_t)a_begin,
-                            (uint32_t)n_a, (uint32_t)b_begin, (uint32_t)n_b, t->sel_individs, threshold, d_hits, capacity,
-                            tally, nullptr, !t->any_missing, pick_stream(t, hip_stream), t->d_marf, pre, bound_thr,
-                            t->opt_boost_mfma ? t->d_cct : nullptr, t->opt_boost_mfma == 2, false, t->last_boost_kernel,
-                            reinterpret_cast<unsigned int *>(t->d_tally + 4), (uint32_t)t->compute_units * 2u,
-                            boost_stagger_ticks(t), t->opt_boost_lut ? t->d_klogk : nullptr, t->d_park, t->compute_units, t->opt_boost_fp4 != 0,
-                            t->sel_cases, t->opt_boost_first_level != 0));
+    gw::BoostLaunch l;
+    boost_launch_of(t, a_begin, n_a, b_begin, n_b, threshold, pick_stream(t, hip_stream), l);
+    l.d_tally = static_cast<unsigned long long *>(d_list);
+    l.d_hits = reinterpret_cast<gw::BoostHit *>(static_cast<char *>(d_list) + GW_BOOST_LIST_HEADER_BYTES);
+    l.max_hits = capacity;
+    l.prefilter = pre; l.bound_threshold = bound_thr; l.first_level = t->opt_boost_first_level != 0;
+    if (pre && (rc = boost_candidates(t, (unsigned long long)n_a * n_b, &l.candidates))) return rc;
+    GW_HIP(gw::launch_boost(l));
     return GW_OK;
 }
 
@@ -1340,7 +1373,7 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_boost_mfma = (int)v;
         return GW_OK;
     case GW_OPT_BOOST_LUT:
-        t->opt_boost_lut = v ? 1 : 0;
+        if (v) return fail(GW_E_INVALID, "boost_lut: the LUT pair kernel was an experiment of round 3 and left the library in round 4 (tools/experiments/)");
         return GW_OK;
     case GW_OPT_BOOST_FIRST_LEVEL:
         t->opt_boost_first_level = v ? 1 : 0;
@@ -1349,8 +1382,11 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         t->opt_boost_fp4 = v ? 1 : 0;
         return GW_OK;
     case GW_OPT_BOOST_STAGGER_US:
-        if (v < -1 || v > 100000) return fail(GW_E_INVALID, "boost_stagger_us must be -1 (auto), 0 (off) or microseconds");
-        t->opt_boost_stagger = (int)v;
+        if (v > 0) return fail(GW_E_INVALID, "boost_stagger_us: the start-up stagger was an experiment of round 3 (no effect) and left the library in round 4");
+        return GW_OK;
+    case GW_OPT_BOOST_CANDIDATES:
+        if (v < 0 || v > (1ll << 28)) return fail(GW_E_INVALID, "boost_candidates must be 0 (auto) or a record count up to 2^28");
+        t->opt_boost_candidates = v;
         return GW_OK;
     case GW_OPT_DEFER_RECORDS:
         if (v < -1 || v > 1) return fail(GW_E_INVALID, "defer_records must be -1 (auto), 0 or 1");
@@ -1394,8 +1430,9 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_PREFILTER_TRIPS: *v = (int64_t)t->prefilter_trips; return GW_OK;
     case GW_OPT_SHORT_ROWS: *v = sh.short_rows; return GW_OK;
     case GW_OPT_DEFER_RECORDS: *v = sh.defer; return GW_OK;
-    case GW_OPT_BOOST_STAGGER_US: *v = boost_stagger_ticks(t) / 100u; return GW_OK;
-    case GW_OPT_BOOST_LUT: *v = t->opt_boost_lut; return GW_OK;
+    case GW_OPT_BOOST_STAGGER_US: *v = 0; return GW_OK;  // retired (round 4)
+    case GW_OPT_BOOST_LUT: *v = 0; return GW_OK;         // retired (round 4)
+    case GW_OPT_BOOST_CANDIDATES: *v = t->opt_boost_candidates; return GW_OK;
     case GW_OPT_BOOST_FP4: *v = t->opt_boost_fp4; return GW_OK;
     case GW_OPT_BOOST_FIRST_LEVEL: *v = t->opt_boost_first_level; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;

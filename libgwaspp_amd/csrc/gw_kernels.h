@@ -118,12 +118,30 @@ struct SnpMarginF {
     // the SNP's share of sum_cells k log2(qb qa / n) when the table has no missing call (boost_bound_split):
     //   ki = sum_g group[g] log2(qa[g])          the SNP as the pair's first marker
     //   kj = sum_g group[g] log2(qb[g] / n)      ... as its second
-    float ki, kj, pad[2];
+    float ki, kj;
+    // round 4, tables without a missing call: tao - 1 from the four corners (gw_boost_dev.h boost_bound_quad_f).  With
+    // d[c][g] = P(status c | genotype g) / P(c) - 1 (0 for an empty genotype class), per group c (0 cases, 1 controls):
+    //   ua[3 c + {0, 1, 2}] = d[c][0] - d[c][1],  d[c][2] - d[c][1],  n d[c][1]                  the SNP as first marker
+    //   vb[3 c + {0, 1, 2}] = P(c) / n x (d[c][0] - d[c][1],  d[c][2] - d[c][1],  d[c][1])       ... as second marker
+    //   ea = max_c max(|ua[3c]|, |ua[3c + 1]|, |d[c][1]|),   eb = sum_c (C_0 |vb[3c]| + C_2 |vb[3c + 1]| + n |vb[3c + 2]|)
+    //   (C_g = everyone with genotype g): ea x eb bounds the sum of the magnitudes of the terms tao - 1 is made of
+    float ea, eb;
+    float ua[6], vb[6];
 };
 struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
     uint32_t snp_a, snp_b;
     double measure;
 };
+// What the matrix-core pair kernels hand to k_boost_finish: the pairs their in-kernel bound could not rule out, with the
+// counted cells.  A record is {snp_a, snp_b, cells of the cases[NP], cells of the controls[NP]} as uint32, NP = 4 (corners,
+// tables without a missing call) or 9; `count` is bumped once per candidate and may exceed `capacity` (the surplus is
+// dropped and reported through d_tally[2], which makes the host repeat the block with every pair in FP64).
+struct BoostCandidateList {
+    uint32_t *records = nullptr;
+    unsigned long long *count = nullptr;
+    unsigned long long capacity = 0;   // in records of the kernel's own size
+};
+inline size_t boost_candidate_bytes(bool nine_cells) { return (2u + 2u * (nine_cells ? 9u : 4u)) * sizeof(uint32_t); }
 
 // selectCaseControl compaction (table5.cpp:443-575) of the whole table
 hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
@@ -134,40 +152,44 @@ hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_
 // d_tally: [0] hits, [1] pairs evaluated, [2] ordered max, [3] ordered min
 hipError_t launch_boost_tables(uint32_t n_entries, uint32_t n_individs, double *d_frac, double *d_xlogx,
                                hipStream_t stream);
-hipError_t launch_boost(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
-                        const SnpMargin *d_mar, const double *d_frac, const double *d_xlogx,
-                        uint32_t a_begin, uint32_t n_a, uint32_t b_begin,
-                        uint32_t n_b, uint32_t n_individs, double threshold, BoostHit *d_hits,
-                        unsigned long long max_hits, unsigned long long *d_tally, double *d_dense,
-                        bool fast, hipStream_t stream,
-                        // FP32 bound first (prefilter), the FP64 measure only for pairs that bound + error bound
-                        // cannot prove to be below `bound_threshold` (the threshold rounded down to float); no
-                        // extremes in d_tally then, d_tally[2] counts evaluated pairs that fall outside the bound's
-                        // error model instead; with d_dense the bound itself is written (diagnostic)
-                        const SnpMarginF *d_marf = nullptr, bool prefilter = false, float bound_threshold = 0.0f,
-                        // tables without a missing call: corners as int8 MFMA dot products (k_boost_mfma)
-                        // over the block-tiled copy of the compacted rows (launch_retile_cc), or null
-                        const u32x4 *d_cct = nullptr,
-                        // force the kernels that keep both groups' accumulators (what case groups >= 65 536 get)
-                        bool both_groups = false,
-                        // diagnostic (prefilter + d_dense): write the bound's error bound instead of the bound
-                        bool dense_err = false,
-                        // char[96] or null: the kernel instantiation the launch went to, as rocprofv3 prints it
-                        char *kernel_name = nullptr,
-                        // start-up stagger of the co-resident workgroups (BoostArgs::ticket in gw_boost_dev.h):
-                        // a device counter, the number of workgroups resident at once, ticks of the 100 MHz clock
-                        unsigned int *d_ticket = nullptr, uint32_t first_gen = 0, uint32_t stagger_ticks = 0,
-                        // k_boost_mfma_lut (cohorts of at most 16 383 without a missing call): k log2 k for
-                        // k = 0 .. n_individs, boost_lut_park_bytes() of scratch, the device's CU count; null = not used
-                        const float *d_klogk = nullptr, uint32_t *d_park = nullptr, int compute_units = 0,
-                        // four-corner tables counted on FP4 operands (k_boost_mfma_fp4) instead of int8 ones
-                        bool fp4 = false,
-                        // prefilter on the FP4 four-corner kernel: the logarithm-free first-level bound ahead of the
-                        // bound proper (boost_bound_quad); needs the case count of the compacted rows.  With d_dense
-                        // (diagnostic) the first-level bound / its error bound is what gets written
-                        uint32_t n_cases = 0, bool first_level = false);
-hipError_t launch_boost_klogk(uint32_t n_entries, float *d_klogk, hipStream_t stream);
-size_t boost_lut_park_bytes(int compute_units);
+// One pair screen: everything launch_boost needs, by name (round 4: this was a list of ~35 positional arguments).
+struct BoostLaunch {
+    // the compacted rows (selectCaseControl), their block-tiled copy for the matrix-core kernels (or null), the margins
+    const uint32_t *d_cc = nullptr;
+    uint64_t cc_stride_w = 0;
+    uint32_t wc = 0, wt = 0;
+    const u32x4 *d_cct = nullptr;
+    const SnpMargin *d_mar = nullptr;
+    const SnpMarginF *d_marf = nullptr;            // needed by the pre-filter and by every matrix-core kernel but k_boost_mfma
+    const double *d_frac = nullptr, *d_xlogx = nullptr;
+    uint32_t n_individs = 0, n_cases = 0;          // of the compacted rows
+    bool no_missing_call = false;                  // the table has no missing call: four corners + margins (table5.cpp:1066-1143)
+    // the block pair [a_begin, +n_a) x [b_begin, +n_b), pairs i < j
+    uint32_t a_begin = 0, n_a = 0, b_begin = 0, n_b = 0;
+    double threshold = 0.0;
+    // results: d_tally [0] hits, [1] pairs evaluated, [2] ordered max / (pre-filter) pairs outside the bound's error
+    // model or candidates lost, [3] ordered min
+    BoostHit *d_hits = nullptr;
+    unsigned long long max_hits = 0;
+    unsigned long long *d_tally = nullptr;
+    double *d_dense = nullptr;                     // n_a x n_b measures (or, diagnostic, bounds), or null
+    // FP32 bound first (prefilter), the FP64 measure only for pairs that bound + error bound cannot prove to be below
+    // `bound_threshold` (the threshold rounded down to float); no extremes in d_tally then
+    bool prefilter = false;
+    float bound_threshold = 0.0f;
+    bool first_level = false;                      // ... with the logarithm-free first level ahead of the bound proper
+    bool dense_err = false;                        // diagnostic (prefilter + d_dense): write the error bound, not the bound
+    // the pairs the in-kernel bound could not rule out (FP4 kernels): records of boost_candidate_bytes() each, a counter
+    BoostCandidateList candidates;
+    // kernel family: matrix_cores 0 = vector ALU, 1 = default, 2 = force the kernels that keep both groups' accumulators;
+    // fp4 = count on FP4 operands where the family has such a kernel
+    int matrix_cores = 1;
+    bool fp4 = true;
+    int compute_units = 0;
+    hipStream_t stream = nullptr;
+    char *kernel_name = nullptr;                   // char[96] or null: the instantiation the launch went to, as rocprofv3 prints it
+};
+hipError_t launch_boost(const BoostLaunch &l);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

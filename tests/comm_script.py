@@ -53,7 +53,7 @@ with gw.GwTable(n, m) as t:
     want, wh, wp, _, _ = t.boost_screen(0, k, 0, k, threshold=30.0, max_hits=cap, extremes=False)
     assert blocks == [(0, k)] and aux0 == 0 and n_pairs == wp == k * (k - 1) // 2 and n_hits == wh > 0
     assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
-    assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, 1>"
+    assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 2, 2, 1, false>"
     lst.close()
     comm.close()
     send.close()

@@ -273,7 +273,10 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
     n_sel = nc + nt
     p, c_lo, c_hi, k0, level = _quad_constants(nc, n_sel)
     # case groups of 65 536 and more: the kernel that keeps both groups' accumulators in registers
-    kname = (lambda lv: f"gw::k_boost_mfma_fp4_both<true, {lv}>") if nc >= 65536 else (lambda lv: f"gw::k_boost_mfma_fp4<true, 2, 2, {lv}>")
+    # (the diagnostic form writes a value per pair: the DENSE instantiations of gw_boost_fp4_full.hip)
+    dn = lambda dense: "true" if dense else "false"
+    kname = ((lambda lv, dense: f"gw::k_boost_mfma_fp4_both<true, {lv}, {dn(dense)}>") if nc >= 65536 else
+             (lambda lv, dense: f"gw::k_boost_mfma_fp4<true, 2, 2, {lv}, {dn(dense)}>"))
     c = max(c_lo, c_hi)
     z = np.linspace(0.0, 1.0, 200_001)
     ent = lambda v: -(np.where(v > 0, v * np.log2(np.maximum(v, 1e-300)), 0.0) + np.where(v < 1, (1 - v) * np.log2(np.maximum(1 - v, 1e-300)), 0.0))
@@ -288,19 +291,30 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
     D = X - p * S
     A1 = k0 + (np.where(D < 0, c_lo, c_hi) * np.where(S > 0, D ** 2 / np.maximum(S, 1.0), 0.0)).sum(axis=(0, 1))
     assert np.all(A <= A1 + 1e-6)                       # the inequality itself, in FP64
+    # round 4: n lg tao enters as n lg e (tao - 1) -- tao (epistasis_func.cpp:424-470) from the same cells, in FP64
+    Ra_c, Ra = X.sum(axis=1), S.sum(axis=1)             # 3, m, m: SNP i's class counts (cases / everyone), same for every j
+    Cb_c, Cb = X.sum(axis=0), S.sum(axis=0)
+    tao = np.zeros((m, m))
+    for Xg, Ra_g, Cb_g, n_g in ((X, Ra_c, Cb_c, float(nc)), (Y, Ra - Ra_c, Cb - Cb_c, float(nt))):
+        for ka in range(3):
+            for kb in range(3):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tao += np.nan_to_num(S[ka, kb] * Ra_g[ka] * Cb_g[kb] / (Ra[ka] * Cb[kb] * n_g))
+    lin_slack = 2.0 * n_sel * (tao - 1.0 - np.log(tao))   # >= 0: what the linearised logarithm adds to the bound
+    assert np.all(lin_slack[np.triu_indices(m, 1)] >= -1e-9)
     with gw.GwTable(n, m) as t:
         t.upload_rows(0, ts)
         t.set_case_control(cs, ct, nc, nt)
         exact = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 4)
         b1 = t.boost_measures(0, m, 0, m)
-        assert t.last_boost_kernel() == kname(level)
+        assert t.last_boost_kernel() == kname(level, True)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 5)
         e1 = t.boost_measures(0, m, 0, m)
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
         iu = np.triu_indices(m, 1)
         ex, bb, ee = exact[iu], b1[iu], e1[iu]
-        want = ex + 2.0 * np.log(2.0) * (A1 - A)[iu]    # the same formula in FP64
+        want = ex + 2.0 * np.log(2.0) * (A1 - A)[iu] + lin_slack[iu]    # the same formula in FP64
         ok = np.isfinite(ex) & np.isfinite(bb) & np.isfinite(ee)
         assert ok.sum() >= 0.9 * np.isfinite(ex).sum()
         dev = np.abs(bb[ok] - want[ok])
@@ -324,7 +338,7 @@ def test_first_level_bound_is_an_upper_bound_within_its_error_model(oracle, n, m
                 t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, first)
                 hits, n_hits, n_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
                 # (the first level is only used where it is selective: thresholds of 25 and more)
-                assert t.last_boost_kernel() == kname(level if first and thr >= 25.0 else 0)
+                assert t.last_boost_kernel() == kname(level if first and thr >= 25.0 else 0, False)
                 assert (n_hits, n_pairs) == (ref_n, ref_pairs) == (int((finite > thr).sum()), m * (m - 1) // 2)
                 assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
         t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, 1)
@@ -393,10 +407,11 @@ def test_new_masks_on_the_same_table_reuse_the_selection_buffers(oracle):
 
 
 @pytest.mark.parametrize("n,m", [(600, 48), (3000, 500), (9000, 1400)])
-def test_lut_kernel_gives_the_same_hit_list(n, m):
-    """GW_OPT_BOOST_LUT = 1 (the persistent kernel with the bound's logarithms in an LDS table, case counts parked in
-    global memory; cohorts <= 16 383 without a missing call) against the default kernel: same hits, same FP64 measures,
-    same pair tally, for block and whole-triangle calls, host and device-list forms; the pre-filter's error model holds."""
+def test_block_calls_on_fp4_equal_the_int8_kernels(n, m):
+    """Block and whole-triangle calls of the pre-filtered screen: the FP4 kernels (candidates out, k_boost_finish behind
+    them) against the int8 one-group-at-a-time kernel (everything in one kernel) -- same hits, same FP64 measures, same
+    pair tally, with the first level (thresholds from 25), without it, and with a threshold every pair passes (every
+    pair becomes a candidate); the pre-filter's error model holds.  The retired options are refused."""
     with gw.GwTable(n, m) as t:
         t.simulate(11, 3, 0)
         t.simulate_phenotype(11)
@@ -404,32 +419,57 @@ def test_lut_kernel_gives_the_same_hit_list(n, m):
                  (5, min(130, m - 5), min(70, m // 2), m - min(70, m // 2))]
         for thr in (30.0, 6.0, -1.0e9):
             for (a, na, b, nb) in calls:
-                t.set_option(gw.capi.OPT_BOOST_LUT, 0)
                 t.set_option(gw.capi.OPT_BOOST_FP4, 0)
                 want, wh, wp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
-                k0 = t.last_boost_kernel()
-                t.set_option(gw.capi.OPT_BOOST_LUT, 1)
-                got, gh, gp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
-                assert k0.startswith("gw::k_boost_mfma_seq<true, 2, 2") and t.last_boost_kernel() == "gw::k_boost_mfma_lut"
-                assert (gh, gp) == (wh, wp)
-                assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
-                # ... and the default: the four corners counted on FP4 operands
-                t.set_option(gw.capi.OPT_BOOST_LUT, 0)
+                assert t.last_boost_kernel().startswith("gw::k_boost_mfma_seq<true, 2, 2")
                 t.set_option(gw.capi.OPT_BOOST_FP4, 1)
                 got4, gh4, gp4, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, extremes=False)
                 # (first level from a threshold of 25: one curvature constant or the two-piece form, by the cohort's balance)
-                assert t.last_boost_kernel() in ([f"gw::k_boost_mfma_fp4<true, 2, 2, {v}>" for v in (1, 2)] if thr >= 25.0 else
-                                                 ["gw::k_boost_mfma_fp4<true, 2, 2, 0>"])
+                assert t.last_boost_kernel() in ([f"gw::k_boost_mfma_fp4<true, 2, 2, {v}, false>" for v in (1, 2)] if thr >= 25.0 else
+                                                 ["gw::k_boost_mfma_fp4<true, 2, 2, 0, false>"])
                 assert (gh4, gp4) == (wh, wp)
                 assert np.array_equal(np.sort(got4, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
         assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
-    # a table with missing calls, or a cohort above 16 383, never takes it
-    with gw.GwTable(2000, 100) as t:
+        for opt in (gw.capi.OPT_BOOST_LUT, gw.capi.OPT_BOOST_STAGGER_US):     # experiments of round 3, no longer in the library
+            with pytest.raises(gw.GwError):
+                t.set_option(opt, 1)
+            t.set_option(opt, 0)
+            assert t.get_option(opt) == 0
+    with gw.GwTable(2000, 100) as t:    # a table with missing calls: nine cells
         t.simulate(11, 3, 655)
         t.simulate_phenotype(11)
-        t.set_option(gw.capi.OPT_BOOST_LUT, 1)
         t.boost_screen(0, 100, 0, 100, extremes=False)
-        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0>"   # nine cells: never the LUT form
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0, false>"
+
+
+def test_candidate_list_overflow_repeats_the_block_in_fp64():
+    """GW_OPT_BOOST_CANDIDATES: a candidate list too small for what the in-kernel bound lets through is reported through
+    the tally (like a violated error model) and the block is repeated with every pair in FP64 -- same hits, one trip."""
+    n, m = 3000, 400
+    with gw.GwTable(n, m) as t:
+        t.simulate(17, 0, 0)
+        t.simulate_phenotype(17)
+        want, wh, wp, _, _ = t.boost_screen(0, m, 0, m, threshold=13.0, extremes=False)
+        assert 100 < wh < 4096 and t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
+        t.set_option(gw.capi.OPT_BOOST_CANDIDATES, 64)
+        got, gh, gp, _, _ = t.boost_screen(0, m, 0, m, threshold=13.0, extremes=False)
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 1
+        assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<false, 2, 2, 0, false>"
+        assert (gh, gp) == (wh, wp)
+        assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
+        # the device-list form reports it in the header (slot 2), where a sharded job's ranks all see it
+        lst = gw.capi.DeviceBuffer(gw.capi.BOOST_LIST_HEADER_BYTES + 16 * 4096)
+        s = t.stream()
+        t.boost_list_init(lst.ptr, s)
+        t.boost_screen_device(0, m, 0, m, lst.ptr, 4096, 13.0, s)
+        _, n_hits, n_pairs, aux0 = gw.parse_boost_list(lst.download(s), 4096)
+        assert aux0 > 0 and n_pairs == wp
+        t.set_option(gw.capi.OPT_BOOST_CANDIDATES, 0)
+        t.boost_list_init(lst.ptr, s)
+        t.boost_screen_device(0, m, 0, m, lst.ptr, 4096, 13.0, s)
+        hits, n_hits, n_pairs, aux0 = gw.parse_boost_list(lst.download(s), 4096)
+        assert aux0 == 0 and (n_hits, n_pairs) == (wh, wp)
+        assert np.array_equal(np.sort(hits[:n_hits], order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
 
 
 @pytest.mark.parametrize("n,m,force", [(3000, 200, True), (9000, 131, True), (140_000, 90, False), (200_000, 70, False)])
@@ -454,8 +494,8 @@ def test_fp4_both_groups_kernel_equals_the_int8_and_vector_kernels(n, m, force):
             res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin,
                          np.sort(pre_hits, order=["snp_a", "snp_b"]), pre_nh, pre_pairs, np.sort(hi_hits, order=["snp_a", "snp_b"]), hi_nh,
                          k_dense, k_pre, t.last_boost_kernel())
-        assert res["fp4"][11] == "gw::k_boost_mfma_fp4_both<false, 0>" and res["fp4"][12] == "gw::k_boost_mfma_fp4_both<true, 0>"
-        assert res["fp4"][13] in ("gw::k_boost_mfma_fp4_both<true, 1>", "gw::k_boost_mfma_fp4_both<true, 2>")
+        assert res["fp4"][11] == "gw::k_boost_mfma_fp4_both<false, 0, true>" and res["fp4"][12] == "gw::k_boost_mfma_fp4_both<true, 0, false>"
+        assert res["fp4"][13] in ("gw::k_boost_mfma_fp4_both<true, 1, false>", "gw::k_boost_mfma_fp4_both<true, 2, false>")
         assert res["int8"][11] == "gw::k_boost_mfma<false>" and res["int8"][12] == "gw::k_boost_mfma<true>"
         for other in ("int8", "valu"):
             assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
@@ -483,7 +523,7 @@ def test_fp4_counting_equals_int8_counting(n, m, missing):
             hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=8.0)
             res[name] = (dense, np.sort(hits, order=["snp_a", "snp_b"]), nh, npairs, vmax, vmin, t.last_boost_kernel())
         shape = "3, 1" if missing else "2, 2"
-        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}, 0>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
+        assert res["fp4"][6] == f"gw::k_boost_mfma_fp4<false, {shape}, 0, false>" and res["int8"][6].startswith(f"gw::k_boost_mfma_seq<false, {shape}")
         for other in ("int8", "valu"):
             assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
             assert np.array_equal(res["fp4"][1], res[other][1]) and res["fp4"][2:6] == res[other][2:6]

@@ -230,7 +230,7 @@ def test_bench_c5_two_ranks_rehearsed_on_one_gpu():
     assert line["config"]["pairs"] == 6000 * 5999 // 2
     assert line["config"]["rehearsal_union_equals_single_screen"] is True
     assert line["config"]["hits_over_30"] > 0
-    assert line["roofline"]["kernel"] == "gw::k_boost_mfma_fp4<true, 2, 2, 1>"
+    assert line["roofline"]["kernel"] == "gw::k_boost_mfma_fp4<true, 2, 2, 1, false>"
 
 
 def test_bench_c5_exchange_through_the_c_abi_on_one_gpu():

@@ -109,6 +109,28 @@ def main():
     print(f"bound1 - measure: min {np.min((b1 - me)[ok]):.3e}  mean {np.mean((b1 - me)[ok]):.3f}  max {np.max((b1 - me)[ok]):.2f}")
     f = np.mean(b1[ok] >= a.threshold - 0.5)
     print(f"first-level bound >= thr - 0.5: {f:.3e} of the pairs")
+    # round 4: the first level with  n lg tao <= n lg e (tao - 1)  (no logarithm at all): extra slack 2 n (tao - 1 - ln tao)
+    t1 = tao[iu] - 1.0
+    lin = 2.0 * nn * (t1 - np.log1p(t1))
+    print(f"tao - 1: mean {t1[ok].mean():.2e}  std {t1[ok].std():.2e}  min {t1[ok].min():.3e}  max {t1[ok].max():.3e};  slack of the "
+          f"linearised logarithm: mean {lin[ok].mean():.3f}  99.9 % {np.quantile(lin[ok], 0.999):.3f}  max {lin[ok].max():.2f}")
+    f_lin = np.mean((b1 + lin)[ok] >= a.threshold - 0.5)
+    print(f"first-level bound with the linearised logarithm >= thr - 0.5: {f_lin:.3e} of the pairs")
+    # ... and with tao itself bounded from per-SNP numbers: tao - 1 = sum_c p(c) sum_ab p(ab) d_ac e_bc, d_ac = p(c|a)/p(c) - 1
+    # for SNP i, e_bc for SNP j;  Cauchy-Schwarz over p(ab):  <= sum_c p(c) sqrt(sum_a p(a) d_ac^2) sqrt(sum_b p(b) e_bc^2)
+    mxs, mys = X.sum(axis=1)[:, :, 0], Y.sum(axis=1)[:, :, 0]        # 3, M: per-SNP class counts of cases / controls
+    tot = mxs + mys
+    cs_bound = np.zeros((m, m))
+    for cnts, pc in ((mxs, case.sum() / nn), (mys, ctrl.sum() / nn)):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = np.where(tot > 0, cnts / np.maximum(tot, 1.0) / pc - 1.0, 0.0)       # 3, M
+        r = np.sqrt(((tot / nn) * d * d).sum(axis=0))                               # M
+        cs_bound += pc * np.outer(r, r)
+    lin_cs = 2.0 * nn * cs_bound[iu]
+    print(f"2 n x the Cauchy-Schwarz bound of tao - 1: mean {lin_cs[ok].mean():.3f}  99 % {np.quantile(lin_cs[ok], 0.99):.3f}  max {lin_cs[ok].max():.2f}"
+          f"  (the true 2 n ln tao: mean {np.mean(2.0 * nn * np.log1p(t1[ok])):.4f})")
+    b_cs = b1 - 2.0 * nn * np.log1p(t1) + lin_cs
+    print(f"first-level bound with tao from per-SNP numbers >= thr - 0.5: {np.mean(b_cs[ok] >= a.threshold - 0.5):.3e} of the pairs; violations of the bound: {int(np.sum((me > b_cs + 1e-9)[ok]))}")
     # groups of 64 pairs as a 32 x 32 tile hands them to a wave: 64 consecutive (i, j) with j fastest, 32-wide tiles
     passing = (bound1 >= a.threshold - 0.5) & np.isfinite(measure)
     mm = (m // 32) * 32

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../libgwaspp_amd/csrc"
 tag=$1; file=$2; shift; shift
 base=$(basename $file .hip)
 mkdir -p build ../exp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -x hip "$@" -c $file -o build/${base}_$tag.o.var
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -x hip "$@" -c $file -o build/${base}_$tag.o.var
 objs=$(ls build/*.o | grep -v "build/${base}.o" | tr '\n' ' ')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared $objs build/${base}_$tag.o.var -ldl -o ../exp/libgwscan_$tag.so
 echo built ../exp/libgwscan_$tag.so

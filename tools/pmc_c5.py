@@ -2,7 +2,7 @@
 """SQ counters of the config-5 pair screen itself (run on the GPU box):
     python3 tools/pmc_c5.py [--snps 100000 --samples 10000] [--tag r03]
 `rocprofv3 --pmc <counters>` (separate passes, nothing else on the rocprofv3 line, the program directly after --) over
-tools/ab_stagger.py with one launch setting; per k_boost_* kernel the sums over all SEs and what follows from them:
+tools/ab_boost.py (the default kernel); per k_boost_* kernel the sums over all SEs and what follows from them:
 matrix-core busy share, vector-ALU issue share, VALU instructions per MFMA, wave-cycle budget.
 -> gpurun_out/<tag>/c5_pmc.json (copied to profiles/<tag>_c5_pmc.json when kept)."""
 import argparse, csv, glob, json, os, shutil, subprocess, sys
@@ -11,8 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--snps", type=int, default=100_000)
 ap.add_argument("--samples", type=int, default=10_000)
 ap.add_argument("--missing-q16", type=int, default=0)
-ap.add_argument("--tag", default="r03")
-ap.add_argument("--stagger-us", default="0")
+ap.add_argument("--tag", default="r04")
 a = ap.parse_args()
 PASSES = [["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
            "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU"],
@@ -23,8 +22,8 @@ for k, counters in enumerate(PASSES):
     d = f"/tmp/pmc_c5_{a.tag}_{k}"
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", "python3",
-           os.path.join(ROOT, "tools", "ab_stagger.py"), "--snps", str(a.snps), "--samples", str(a.samples),
-           "--missing-q16", str(a.missing_q16), "--us", a.stagger_us, "--rounds", "2"]
+           os.path.join(ROOT, "tools", "ab_boost.py"), "--snps", str(a.snps), "--samples", str(a.samples),
+           "--missing-q16", str(a.missing_q16), "--rounds", "2"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if r.returncode != 0 or not files:
@@ -55,8 +54,8 @@ for name, e in out.items():
 path = os.path.join(ROOT, "gpurun_out", a.tag, "c5_pmc.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 with open(path, "w") as fh:
-    json.dump({"command": "rocprofv3 --pmc <one pass per list> --output-format csv -- python3 tools/ab_stagger.py --snps %d --samples %d --missing-q16 %d --us %s --rounds 2"
-               % (a.snps, a.samples, a.missing_q16, a.stagger_us), "passes": PASSES, "notes": notes,
+    json.dump({"command": "rocprofv3 --pmc <one pass per list> --output-format csv -- python3 tools/ab_boost.py --snps %d --samples %d --missing-q16 %d --rounds 2"
+               % (a.snps, a.samples, a.missing_q16), "passes": PASSES, "notes": notes,
                "units": "sums over all SEs / XCDs per launch (averaged over the launches seen); SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_* in units of 4 cycles; "
                         "SQ_VALU_MFMA_BUSY_CYCLES in cycles (32 per v_mfma_i32_32x32x32_i8)",
                "pairs_per_launch": pairs, "kernels": res}, fh, indent=1)
