@@ -7,6 +7,9 @@
 //   bit 2  operand rows refilled from memory inside the loop (a 2 MB table, L2-resident), else loaded once
 //   bit 3  sched_group_barrier interleave (1 MFMA : 4 VALU)
 //   bit 4  the expansion mask as a VGPR instead of an SGPR
+//   bit 5  the refills addressed as uniform base (SGPR pair) + per-lane 32-bit offset instead of per-lane 64-bit pointers
+//   bit 6  only the B row is refilled (2 of the 6 loads per 32 MFMAs), bit 7  only the A rows (4 of 6)
+//   bit 8  the refills as dwordx2 loads (twice as many instructions, the same bytes)
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_loop_probe tools/mfma_loop_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -27,12 +30,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, int rounds, int sc_half, int sc_one, int sc_two,
                                                 uint32_t chunk_mask) {
-    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16;
+    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16, SADDR = MODE & 32, ONLY_B = MODE & 64, ONLY_A = MODE & 128, X2 = MODE & 256;
     constexpr int TA = 2, NV = 2, NP = 4, NT = 8, RING = 4;
     const uint32_t t = threadIdx.x, lane = t & 63u, fr = lane & 31u, fh = lane >> 5, wave = t >> 6;
     const u32x4 *ga[TA], *gb;
     for (int ta = 0; ta < TA; ++ta) ga[ta] = tbl + ((blockIdx.x * 7u + wave * 3u + ta) & 15u) * 128u * 64u + fr * 2u + fh;
     gb = tbl + ((blockIdx.x * 5u + wave + 9u) & 15u) * 128u * 64u + fr * 2u + fh;
+    // SADDR: the row block is wave-uniform (readfirstlane), the lane adds 16 (2 fr + fh) bytes
+    const uint32_t lane_off = (fr * 2u + fh) * 16u;
+    uint64_t sa[TA], sb;
+    for (int ta = 0; ta < TA; ++ta)
+        sa[ta] = (uint64_t)tbl + (uint64_t)__builtin_amdgcn_readfirstlane((int)(((blockIdx.x * 7u + wave * 3u + ta) & 15u) * 128u * 64u)) * 16u;
+    sb = (uint64_t)tbl + (uint64_t)__builtin_amdgcn_readfirstlane((int)(((blockIdx.x * 5u + wave + 9u) & 15u) * 128u * 64u)) * 16u;
     f32x16 acc[TA][NP];
     for (int ta = 0; ta < TA; ++ta)
         for (int c = 0; c < NP; ++c)
@@ -101,8 +110,21 @@ __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, i
             if (LOADS) {
                 for (int d = 0; d < 2; ++d) {
                     const uint64_t nxt = (uint64_t)((c0 + k + d + RING) & chunk_mask) * 128u;
-                    for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
-                    ub[k + d] = gb[nxt];
+                    if (SADDR) {
+                        for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = *(const u32x4 *)((const char *)(sa[ta] + nxt * 16u) + lane_off);
+                        ub[k + d] = *(const u32x4 *)((const char *)(sb + nxt * 16u) + lane_off);
+                    } else if (X2) {
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        for (int ta = 0; ta < TA; ++ta) {
+                            const u32x2 lo = ((const u32x2 *)(ga[ta] + nxt))[0], hi = ((const u32x2 *)(ga[ta] + nxt))[1];
+                            ua[k + d][ta] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        }
+                        const u32x2 lo = ((const u32x2 *)(gb + nxt))[0], hi = ((const u32x2 *)(gb + nxt))[1];
+                        ub[k + d] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    } else {
+                        if (!ONLY_B) for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
+                        if (!ONLY_A) ub[k + d] = gb[nxt];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -152,6 +174,10 @@ int main() {
         run<15>("  + operand rows refilled from L2 in the loop (the kernel's loop)", dtbl, dout, w, cus);
         run<31>("  + mask in a VGPR", dtbl, dout, w, cus);
         run<7>("the kernel's loop without the interleave pattern", dtbl, dout, w, cus);
+        run<5>("  ... and without the sign-bit shifts", dtbl, dout, w, cus);
+        run<7 + 64>("the kernel's loop without the pattern, 2 of the 6 refills", dtbl, dout, w, cus);
+        run<7 + 128>("the kernel's loop without the pattern, 4 of the 6 refills", dtbl, dout, w, cus);
+        run<7 + 256>("the kernel's loop without the pattern, refills as 12 dwordx2 loads", dtbl, dout, w, cus);
     }
     return 0;
 }

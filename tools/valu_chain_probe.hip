@@ -28,6 +28,13 @@ __global__ void __launch_bounds__(256) k_chain(float *out, float seed) {
                 else if (KIND == 2) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
                 else if (KIND == 3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(y), "v"(x));
                 else if (KIND == 4) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r[i]) : "v"(y));
+                else if (KIND == 5) {  // one v_rcp_f32 and three v_fma_f32 on other registers: do they overlap?
+                    if ((i & 3) == 0) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+                    else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(y), "v"(x));
+                } else if (KIND == 6) {  // one v_rcp_f32 and one v_fma_f32
+                    if ((i & 1) == 0) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[i]));
+                    else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(y), "v"(x));
+                }
             }
         }
     }
@@ -80,5 +87,7 @@ int main() {
     all<2>("v_rcp_f32", p.multiProcessorCount, ghz);
     all<3>("v_bitop3_b32", p.multiProcessorCount, ghz);
     all<4>("v_sub_f32", p.multiProcessorCount, ghz);
+    run<5, 16>("rcp + 3 fma", p.multiProcessorCount, ghz);   // serial: (8.1 + 3 x 2.5) / 4 = 3.9 per instruction; overlapped: ~2.5
+    run<6, 16>("rcp + 1 fma", p.multiProcessorCount, ghz);   // serial: (8.1 + 2.5) / 2 = 5.3; overlapped: ~4.05
     return 0;
 }
