@@ -427,7 +427,33 @@ def bench_pairs(args, rank, world, local_rank, dist, steps=None, warmup=None, wi
                                                                 np.allclose(flat, want, rtol=1e-10, atol=1e-8,
                                                                             equal_nan=True))}
     table.close()
+    if out is not None and world == 1 and not args.snps and not args.no_cpu_baseline:
+        out["config"]["compute_boost"] = compute_boost_end_to_end(n_samples, n_snps, local_rank)
     return out
+
+
+def compute_boost_end_to_end(n_samples, n_snps, device):
+    """computeBoost as a user of the drop-in table runs it (algorithms/epistasis_func.cpp:349-506): selectCaseControl +
+    computeMargins, the pre-screen of all pairs, stage 2 (computeGTest) -- through the C++ host (`gwas_hip --time-boost`,
+    a child process with a table of its own; this process has closed its table).  Untimed side measurement: `value` is
+    the screen.  The one-thread host form of stage 2 (round 3's) is timed beside the device form as its baseline."""
+    cli = os.path.join(ROOT, "libgwaspp_amd", "bin", "gwas_hip")
+    if not os.path.exists(cli):
+        return {"error": f"{cli} is not built (make -C libgwaspp_amd/host)"}
+    r = subprocess.run([cli, "--simulate", str(n_samples), str(n_snps), "--seed", hex(SEED), "--device", str(device), "--time-boost"],
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(lines[-1])
+    return {"compute_boost_end_to_end_ms": d["compute_boost_end_to_end_s"] * 1e3,
+            "select_and_margins_ms": d["select_and_margins_s"] * 1e3, "screen_ms": d["screen_s"] * 1e3,
+            "stage2_device_ms": d["stage2_device_s"] * 1e3,
+            "stage2_one_host_thread_ms": d["stage2_one_host_thread_s"] * 1e3,
+            "hits_over_30": d["hits_over_30"], "hits_over_30_after_stage2": d["hits_over_30_after_stage2"],
+            "max_abs_diff_device_vs_host_stage2": d["max_abs_diff_device_vs_host_stage2"],
+            "what": "wall clock of one computeBoost through HipGenotypeTable (second pass of two): host-side walk of the per-row "
+                    "margins getter, gw_boost_screen incl. the copy of the hits, gw_boost_gtest incl. its copies"}
 
 
 def main():

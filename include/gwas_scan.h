@@ -264,6 +264,21 @@ int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begi
 int gw_boost_list_init(gw_table *t, void *d_list, void *hip_stream);
 int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
                            double threshold, void *d_list, uint64_t capacity, void *hip_stream);
+/* BOOST stage 2 on the device: computeGTest (algorithms/epistasis_func.cpp:508-704) for n pairs -- per pair the two
+ * 3 x 3 case / control tables from the compacted rows (what getCaseControlContingencyTable(i, j, margins_i, margins_j, ccct)
+ * hands the reference, table5.cpp:989-1150), the homogeneous-association model fitted by iterative proportional fitting in
+ * FP64 exactly as the reference iterates it, measure[k] = the exact interaction measure (the value the reference writes back
+ * into the pair, :684-685) and z[k] = the difference of the allelic log odds ratios over its standard error (:686-701).
+ * Only snp_a / snp_b of pairs[k] are read.  The reference's fitting loop has no iteration bound; this one stops after 2^24
+ * sweeps and counts such pairs in *n_unsettled (may be NULL) -- tables with missing calls need 10^4 sweeps at the median
+ * and millions at worst in the reference's formulation, tables without a missing call tens.  Needs gw_table_set_case_control. */
+int gw_boost_gtest(gw_table *t, const gw_boost_hit *pairs, uint64_t n, double *measure, double *z, uint64_t *n_unsettled);
+/* ... for a hit list in HBM as gw_boost_screen_device leaves it (header + hits; capacity as given there): the pairs are the
+ * first min(n_hits, capacity) records, d_measure_z receives {measure, z} per record (2 * capacity doubles of device memory),
+ * d_status (8 bytes of device memory the caller has zeroed, or NULL) is incremented per unsettled pair.  Enqueued on
+ * `hip_stream` behind the screens, nothing returns to the host. */
+int gw_boost_gtest_device(gw_table *t, const void *d_list, uint64_t capacity, void *d_measure_z, void *d_status,
+                          void *hip_stream);
 /* the kernel instantiation the handle's last pair screen was dispatched to, as rocprofv3 prints it */
 const char *gw_last_boost_kernel(const gw_table *t);
 /* every measure of a (small) block, row-major n_a x n_b; NaN where i >= j */

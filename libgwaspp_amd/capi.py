@@ -95,7 +95,7 @@ EXPORTS = [
     "gw_scan_case_control", "gw_scan_case_control_device", "gw_scan_distribution",
     "gw_scan_distribution_device", "gw_scan_margins", "gw_pair_contingency", "gw_pair_case_control_contingency",
     "gw_boost_screen", "gw_boost_measures", "gw_table_download_selected", "gw_boost_list_init",
-    "gw_boost_screen_device", "gw_last_boost_kernel", "gw_shard_pair_blocks", "gw_table_replicate",
+    "gw_boost_screen_device", "gw_boost_gtest", "gw_boost_gtest_device", "gw_last_boost_kernel", "gw_shard_pair_blocks", "gw_table_replicate",
     "gw_comm_allgather", "gw_comm_broadcast", "gw_device_memset",
     "gw_timer_start", "gw_timer_stop", "gw_stream_read_probe", "gw_synchronize", "gw_last_scan_kernel",
     "gw_shard_range", "gw_comm_new_id", "gw_comm_create", "gw_comm_destroy", "gw_comm_gather", "gw_comm_synchronize",
@@ -145,6 +145,8 @@ def library() -> C.CDLL:
     L.gw_table_download_selected.argtypes = [vp, C.c_uint64, C.c_uint64, u16p, u32p, u32p]
     L.gw_boost_list_init.argtypes = [vp, vp, vp]
     L.gw_boost_screen_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, vp, C.c_uint64, vp]
+    L.gw_boost_gtest.argtypes = [vp, vp, C.c_uint64, f64p, f64p, C.POINTER(C.c_uint64)]
+    L.gw_boost_gtest_device.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
     L.gw_last_boost_kernel.argtypes = [vp]
     L.gw_last_boost_kernel.restype = C.c_char_p
     L.gw_shard_pair_blocks.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -277,6 +279,9 @@ class DeviceBuffer:
         out = np.zeros(self.nbytes, dtype=np.uint8)
         _check(self._L.gw_device_download(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
         return out
+
+    def memset(self, value: int = 0, stream: int | None = None):
+        _check(self._L.gw_device_memset(self.device, self.ptr, value, self.nbytes, stream))
 
     def close(self):
         if self.ptr:
@@ -483,6 +488,26 @@ class GwTable:
         """Appends the block's hits to the device list at d_list (BOOST_LIST_HEADER_BYTES + 16 * capacity bytes);
         enqueued on `stream`, not synchronised."""
         _check(self._L.gw_boost_screen_device(self._h, a_begin, n_a, b_begin, n_b, threshold, d_list, capacity, stream))
+
+    def boost_gtest(self, pairs):
+        """BOOST stage 2 (computeGTest) for the pairs of a hit array (dtype BOOST_HIT_DTYPE) or an (n, 2) integer array
+        -> (measure[n], z[n], n_unsettled)."""
+        if pairs.dtype != BOOST_HIT_DTYPE:
+            ij = np.asarray(pairs)
+            pairs = np.zeros(ij.shape[0], dtype=BOOST_HIT_DTYPE)
+            pairs["snp_a"], pairs["snp_b"] = ij[:, 0], ij[:, 1]
+        pairs = np.ascontiguousarray(pairs)
+        n = pairs.shape[0]
+        measure, z = np.zeros(n, dtype=np.float64), np.zeros(n, dtype=np.float64)
+        unsettled = C.c_uint64(0)
+        _check(self._L.gw_boost_gtest(self._h, pairs.ctypes.data, n, measure.ctypes.data_as(C.POINTER(C.c_double)),
+                                      z.ctypes.data_as(C.POINTER(C.c_double)), C.byref(unsettled)))
+        return measure, z, unsettled.value
+
+    def boost_gtest_device(self, d_list: int, capacity: int, d_measure_z: int, d_status: int | None = None,
+                           stream: int | None = None):
+        """... for a hit list in HBM (gw_boost_screen_device's layout); {measure, z} per record go to d_measure_z."""
+        _check(self._L.gw_boost_gtest_device(self._h, d_list, capacity, d_measure_z, d_status, stream))
 
     def last_boost_kernel(self) -> str:
         return self._L.gw_last_boost_kernel(self._h).decode()

@@ -22,6 +22,7 @@
 // device code (measure, bound, operand expansion) in gw_boost_dev.h.
 #include "gw_boost_dev.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -183,6 +184,155 @@ hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_
     if (n_rows == 0) return hipSuccess;
     hipLaunchKernelGGL(k_margins, dim3((n_rows + 255u) / 256u), dim3(256), 0, stream, d_counts, n_rows,
                        n_individs, d_mar, d_marf);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// BOOST stage 2 on the device: computeGTest (algorithms/epistasis_func.cpp:508-704) for a list of pairs.
+//   k_gtest_tables  one wave per pair: the two 3 x 3 tables from the compacted rows (selectCaseControl's planes, so a sample
+//                   in both masks is a case only, as in the reference's compacted tables table5.cpp:989-1064)
+//   k_gtest         one lane per pair: iterative proportional fitting of the homogeneous-association model in FP64, the
+//                   exact interaction measure, the difference of the allelic log odds ratios over its standard error --
+//                   operation for operation the oracle's gwo_gtest (-ffp-contract=off on both sides)
+// The reference's `while (muError > 0.001)` has no bound; a kernel must have one: GTEST_MAX_ITER sweeps, after which
+// the pair is evaluated as it stands and counted in status[0].  The bound is far out because the reference's own loop is
+// slow where the tables have missing calls: the pair table then does not add up to the SNPs' margins, the fit creeps
+// (error ~ 1 / sweep) and takes 10^4 sweeps at the median and up to 3 x 10^6 for a pair at 1 % missing calls
+// (tests/test_gpu_boost.py measures against the oracle there); tables without a missing call settle in tens of sweeps.
+// ---------------------------------------------------------------------------
+constexpr int GTEST_MAX_ITER = 1 << 24;
+
+__global__ void __launch_bounds__(256) k_gtest_tables(const uint32_t *cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt,
+                                                      const uint32_t *pairs, uint32_t pair_stride, const unsigned long long *n_ptr,
+                                                      unsigned long long n_max, uint32_t *tabs) {
+    const unsigned long long n = n_ptr ? (*n_ptr < n_max ? *n_ptr : n_max) : n_max;
+    const uint32_t lane = threadIdx.x & 63u, wpb = blockDim.x >> 6;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * wpb + (threadIdx.x >> 6); p < n; p += (unsigned long long)gridDim.x * wpb) {
+        const uint32_t i = pairs[p * pair_stride], j = pairs[p * pair_stride + 1];
+        const uint32_t *ri = cc + (uint64_t)i * cc_stride_w, *rj = cc + (uint64_t)j * cc_stride_w;
+        uint32_t cnt[18];
+#pragma unroll
+        for (int c = 0; c < 18; ++c) cnt[c] = 0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t words = g == 0 ? wc : wt, base = g == 0 ? 0u : 2u * wc;
+            for (uint32_t w = lane; w < words; w += 64u) {
+                const uint32_t a0 = ri[base + w], a1 = ri[base + words + w], b0 = rj[base + w], b1 = rj[base + words + w];
+                const uint32_t ca[3] = {a0 & ~a1, a1 & ~a0, a0 & a1}, cb[3] = {b0 & ~b1, b1 & ~b0, b0 & b1};
+#pragma unroll
+                for (int x = 0; x < 3; ++x)
+#pragma unroll
+                    for (int y = 0; y < 3; ++y) cnt[9 * g + 3 * x + y] += (uint32_t)__popc(ca[x] & cb[y]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 18; ++c) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt[c] += __shfl_xor(cnt[c], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 18; ++c) tabs[p * 18u + c] = cnt[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_gtest(const uint32_t *tabs, const uint32_t *pairs, uint32_t pair_stride,
+                                              const unsigned long long *n_ptr, unsigned long long n_max, const SnpMargin *mar,
+                                              uint32_t n_individs, double *out, unsigned long long *status) {
+    const unsigned long long n = n_ptr ? (*n_ptr < n_max ? *n_ptr : n_max) : n_max;
+    const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t *ca_tab = tabs + p * 18u, *co_tab = ca_tab + 9;
+    const SnpMargin *m1 = mar + pairs[p * pair_stride], *m2 = mar + pairs[p * pair_stride + 1];
+    uint32_t f1c[3], f1t[3], f2c[3], f2t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f1c[k] = m1->cases[k]; f1t[k] = m1->ctrls[k]; f2c[k] = m2->cases[k]; f2t[k] = m2->ctrls[k]; }
+    double mu_ca[9], mu_co[9], old_ca[9], old_co[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { mu_ca[i] = mu_co[i] = 1.0; old_ca[i] = old_co[i] = 0.0; }
+    double err = 18.0 * fabs(mu_ca[0] - old_ca[0]);  // :552-556 (the reference adds the first element eighteen times)
+    int iter = 0;
+    while (err > 0.001 && iter < GTEST_MAX_ITER) {
+        ++iter;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { old_ca[i] = mu_ca[i]; old_co[i] = mu_co[i]; }
+        double ik[6] = {0, 0, 0, 0, 0, 0}, jk[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {  // :571-598
+                const int i = 3 * a + b;
+                const uint32_t tot = ca_tab[i] + co_tab[i];
+                const double mij = mu_ca[i] + mu_co[i];
+                if (mij > 0) {
+                    mu_ca[i] = mu_ca[i] * (tot) / mij;
+                    mu_co[i] = mu_co[i] * (tot) / mij;
+                } else {
+                    mu_ca[i] = 0;
+                    mu_co[i] = 0;
+                }
+                ik[a] += mu_ca[i]; ik[3 + a] += mu_co[i];
+                jk[b] += mu_ca[i]; jk[3 + b] += mu_co[i];
+            }
+        err = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {  // :611-645
+            const double t1 = ik[a] > 0 ? f1c[a] / ik[a] : 0.0;
+            const double t2 = ik[3 + a] > 0 ? f1t[a] / ik[3 + a] : 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int i = 3 * a + b;
+                const double t3 = jk[b] > 0 ? f2c[b] / jk[b] : 0.0;
+                const double t4 = jk[3 + b] > 0 ? f2t[b] / jk[3 + b] : 0.0;
+                mu_ca[i] = mu_ca[i] * (t1)*t3;
+                mu_co[i] = mu_co[i] * (t2)*t4;
+                err += fabs(mu_ca[i] - old_ca[i]);
+                err += fabs(mu_co[i] - old_co[i]);
+            }
+        }
+    }
+    if (err > 0.001 && status) atomicAdd(&status[0], 1ull);
+    double tao = 0.0, im = 0.0;  // :648-683
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t ca = ca_tab[i], co = co_tab[i];
+        double t1, t2;
+        if (ca > 0) { t1 = (double)ca / n_individs; im += t1 * log(t1); } else t1 = 0.0;
+        if (mu_ca[i] > 0) { t2 = mu_ca[i] / n_individs; im += -t1 * log(t2); tao += t2; }
+        if (co > 0) { t1 = (double)co / n_individs; im += t1 * log(t1); } else t1 = 0.0;
+        if (mu_co[i] > 0) { t2 = mu_co[i] / n_individs; im += -t1 * log(t2); tao += t2; }
+    }
+    out[2 * p] = (im + log(tao)) * n_individs * 2.0;
+    // allelic joint distribution and the odds-ratio z value, :686-701 (uint arithmetic, as the reference)
+    uint32_t aj[8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t *t = g == 0 ? ca_tab : co_tab;  // 3 x 3 here: the reference's 4 x 4 indices 0,1,2,4,5,6,8,9,10
+        aj[4 * g + 0] = (t[0] << 2) + (t[1] << 1) + (t[3] << 1) + t[4];
+        aj[4 * g + 1] = (t[2] << 2) + (t[1] << 1) + (t[5] << 1) + t[4];
+        aj[4 * g + 2] = (t[6] << 2) + (t[7] << 1) + (t[3] << 1) + t[4];
+        aj[4 * g + 3] = (t[8] << 2) + (t[7] << 1) + (t[5] << 1) + t[4];
+    }
+    const double or_aff = log((double)(aj[0] * aj[3]) / (double)(aj[1] * aj[2]));
+    const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
+    const double or_unf = log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
+    const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
+    out[2 * p + 1] = (or_aff - or_unf) / sqrt(v_aff + v_unf);
+}
+
+hipError_t launch_boost_gtest(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, const SnpMargin *d_mar,
+                              uint32_t n_individs, const uint32_t *d_pairs, uint32_t pair_stride,
+                              const unsigned long long *d_n, unsigned long long n_max, uint32_t *d_tabs, double *d_out,
+                              unsigned long long *d_status, int compute_units, hipStream_t stream) {
+    if (n_max == 0) return hipSuccess;
+    const unsigned waves = (unsigned)std::min<unsigned long long>(n_max, (unsigned long long)(compute_units > 0 ? compute_units : 256) * 32ull);
+    hipLaunchKernelGGL(k_gtest_tables, dim3((waves + 3u) / 4u), dim3(256), 0, stream, d_cc, cc_stride_w, wc, wt, d_pairs, pair_stride,
+                       d_n, n_max, d_tabs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gtest, dim3((unsigned)((n_max + 63ull) / 64ull)), dim3(64), 0, stream, d_tabs, d_pairs, pair_stride, d_n, n_max,
+                       d_mar, n_individs, d_out, d_status);
     return hipGetLastError();
 }
 

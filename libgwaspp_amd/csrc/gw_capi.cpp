@@ -1162,6 +1162,80 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
     return GW_OK;
 }
 
+// ---- BOOST stage 2 on the device: computeGTest (epistasis_func.cpp:508-704) --------------------------------------------
+namespace {
+// scratch for n pairs: 18 uint32 of tables + 2 doubles of results each, + the status word (grow-only, in the handle's
+// 64-bit scratch so that the doubles are aligned)
+int gtest_scratch(gw_table *t, uint64_t n, uint32_t **tabs, double **out, unsigned long long **status) {
+    const size_t out_bytes = (size_t)n * 2u * sizeof(double), tab_bytes = (size_t)n * 18u * sizeof(uint32_t);
+    int rc = ensure_scratch(t, tab_bytes, out_bytes + 16u);
+    if (rc) return rc;
+    *tabs = t->d_scratch32;
+    *status = reinterpret_cast<unsigned long long *>(t->d_scratch64);
+    *out = t->d_scratch64 + 2;
+    return GW_OK;
+}
+}  // namespace
+
+int gw_boost_gtest(gw_table *t, const gw_boost_hit *pairs, uint64_t n, double *measure, double *z, uint64_t *n_unsettled) {
+    if (!t || ((!pairs || !measure || !z) && n)) return fail(GW_E_INVALID, "NULL argument");
+    if (n_unsettled) *n_unsettled = 0;
+    if (n == 0) return GW_OK;
+    if (n > 0x0FFFFFFFull) return fail(GW_E_RANGE, "too many pairs in one call");
+    for (uint64_t k = 0; k < n; ++k)
+        if (pairs[k].snp_a >= t->tv.n_snps || pairs[k].snp_b >= t->tv.n_snps)
+            return fail(GW_E_RANGE, "pair %llu names a SNP outside the table", (unsigned long long)k);
+    int rc = ensure_selected(t);
+    if (rc) return rc;
+    if ((rc = use_device(t))) return rc;
+    uint32_t *d_tabs;
+    double *d_out;
+    unsigned long long *d_status;
+    if ((rc = gtest_scratch(t, n, &d_tabs, &d_out, &d_status))) return rc;
+    // the pairs travel as the hit records they are (16 bytes: snp_a, snp_b, the screen's measure)
+    const size_t need = (size_t)n * sizeof(gw_boost_hit);
+    if (need > t->hits_buf_bytes) {
+        if (t->d_hits_buf) GW_HIP(hipFree(t->d_hits_buf));
+        t->d_hits_buf = nullptr;
+        t->hits_buf_bytes = 0;
+        GW_HIP(hipMalloc(&t->d_hits_buf, need));
+        t->hits_buf_bytes = need;
+    }
+    GW_HIP(hipMemcpyAsync(t->d_hits_buf, pairs, need, hipMemcpyHostToDevice, t->stream));
+    GW_HIP(hipMemsetAsync(d_status, 0, 16, t->stream));
+    GW_HIP(gw::launch_boost_gtest(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->sel_individs,
+                                  static_cast<const uint32_t *>(t->d_hits_buf), 4u, nullptr, n, d_tabs, d_out, d_status,
+                                  t->compute_units, t->stream));
+    std::vector<double> both((size_t)n * 2u);
+    unsigned long long status[2] = {0, 0};
+    GW_HIP(hipMemcpyAsync(both.data(), d_out, both.size() * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipMemcpyAsync(status, d_status, sizeof status, hipMemcpyDeviceToHost, t->stream));
+    GW_HIP(hipStreamSynchronize(t->stream));
+    for (uint64_t k = 0; k < n; ++k) { measure[k] = both[2 * k]; z[k] = both[2 * k + 1]; }
+    if (n_unsettled) *n_unsettled = status[0];
+    return GW_OK;
+}
+
+int gw_boost_gtest_device(gw_table *t, const void *d_list, uint64_t capacity, void *d_measure_z, void *d_status,
+                          void *hip_stream) {
+    if (!t || !d_list || !d_measure_z) return fail(GW_E_INVALID, "NULL argument");
+    if (capacity == 0) return GW_OK;
+    if (capacity > 0x0FFFFFFFull) return fail(GW_E_RANGE, "too many pairs in one call");
+    int rc = ensure_selected(t);
+    if (rc) return rc;
+    if ((rc = use_device(t))) return rc;
+    uint32_t *d_tabs;
+    double *d_unused;
+    unsigned long long *d_own_status;
+    if ((rc = gtest_scratch(t, capacity, &d_tabs, &d_unused, &d_own_status))) return rc;
+    const unsigned long long *d_n = static_cast<const unsigned long long *>(d_list);   // header slot 0: hits found
+    const uint32_t *d_hits = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_list) + GW_BOOST_LIST_HEADER_BYTES);
+    GW_HIP(gw::launch_boost_gtest(t->d_cc, t->cc_stride_w, t->wc, t->wt, t->d_mar, t->sel_individs, d_hits, 4u, d_n, capacity,
+                                  d_tabs, static_cast<double *>(d_measure_z), static_cast<unsigned long long *>(d_status),
+                                  t->compute_units, pick_stream(t, hip_stream)));
+    return GW_OK;
+}
+
 // ---- replication of a table's rows over the ranks of a communicator (the pair screen needs every row on every GPU)
 int gw_table_replicate(gw_table *t, gw_comm *c, int root, void *hip_stream) {
     if (!t || !c) return fail(GW_E_INVALID, "NULL argument");

@@ -190,6 +190,13 @@ struct BoostLaunch {
     char *kernel_name = nullptr;                   // char[96] or null: the instantiation the launch went to, as rocprofv3 prints it
 };
 hipError_t launch_boost(const BoostLaunch &l);
+// BOOST stage 2 (computeGTest, epistasis_func.cpp:508-704) for the pairs {d_pairs[k * pair_stride], d_pairs[k * pair_stride + 1]},
+// k < min(*d_n, n_max) (d_n null: n_max): d_tabs = 18 uint32 per pair of scratch, d_out[2k] = measure, [2k + 1] = z,
+// d_status[0] += pairs whose fit did not settle within the sweep cap
+hipError_t launch_boost_gtest(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, const SnpMargin *d_mar,
+                              uint32_t n_individs, const uint32_t *d_pairs, uint32_t pair_stride,
+                              const unsigned long long *d_n, unsigned long long n_max, uint32_t *d_tabs, double *d_out,
+                              unsigned long long *d_status, int compute_units, hipStream_t stream);
 // bytes: ((n_snps + 63) / 64) * 64 * ((wc + wt) / 4) * 32
 hipError_t launch_retile_cc(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, uint32_t n_snps,
                             u32x4 *d_cct, hipStream_t stream);

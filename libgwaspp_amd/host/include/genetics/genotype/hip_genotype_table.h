@@ -84,13 +84,20 @@ public:
     // computeBoost's whole pre-screening loop (algorithms/epistasis_func.cpp:393-486) in one device
     // pass: pairs (i, j, measure) with measure > threshold, in the reference's (i, j) visiting order
     void boostScreen(double threshold, std::vector<std::pair<std::pair<uint, uint>, double> > &passing);
+    // computeGTest (algorithms/epistasis_func.cpp:508-704) for every pair of `pairs` on the device (gw_boost_gtest): the
+    // IPF-fitted measure replaces .second, zval receives the odds-ratio z values.  setHostGTest(true) keeps stage 2 on one
+    // host thread over device-fetched tables (round 3's form: the baseline `gwas_hip --time-boost` times beside it)
+    void boostGTest(std::vector<std::pair<std::pair<uint, uint>, double> > &pairs, std::vector<double> &zval);
+    void setHostGTest(bool on) { host_gtest = on; }
+    bool hostGTest() const { return host_gtest; }
     void setScanWindow(uint rows) { window = rows ? rows : 1; invalidate(); }
     // scan window k+1 on a worker thread while the caller walks window k (on by default)
     void setPrefetch(bool on) { drop_prefetch(); prefetch = on; }
     // the reference's CaseControlSet has no change counter, so a set edited in place is recognised from its mask
-    // bytes: all of them at selectCaseControl() and at every new window of rows; on the calls in between object +
-    // counts, and 32 sampled words per mask on every 16th (the reference's loops never edit a set mid-walk).  true = compare
-    // all bytes on every getter call (N/4 bytes of host reads per call)
+    // bytes: all of them at selectCaseControl(), at every new window of rows and whenever a getter call is not the
+    // strict successor (row + 1) of the previous one -- so a second walk from row 0 after a relabelling sees it; inside
+    // a strictly sequential walk object + counts, and 32 sampled words per mask on every 16th call (the reference's
+    // loops never edit a set mid-walk).  true = compare all bytes on every getter call (N/4 bytes of host reads per call)
     void setMaskCheckEveryCall(bool on) { check_every_call = on; }
     gw_table *handle() { settle(); return tbl; }
     // the rows were changed through handle() (gw_table_simulate, gw_table_upload_rows): drop every host cache
@@ -143,6 +150,8 @@ protected:
     uint64_t installed_sample[2];
     bool check_every_call;
     uint calls_since_sample;
+    uint last_cc_row;   // the row of the previous masked getter call (0xFFFFFFFF: none)
+    bool host_gtest;
 
     // pair getters: the reference's loops walk (i, j), (i, j+1), ... -- a run of pairs of the same first marker
     // is fetched in one launch (the run grows x4 while the walk stays sequential, 1 .. 4096 pairs)

@@ -119,8 +119,15 @@ void gtestOnePair(const CONTIN_TABLE_T &contin_ca, const CONTIN_TABLE_T &contin_
 
 void computeGTest(GenoTable &gt, marginal_information *pMargins, uint nIndivids,
                   std::vector<SNPInteractionPair> &passingThreshold, std::vector<double> &zval) {
-    if (HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt)) {
-        // the tables of all passing pairs in one device launch instead of one per pair
+    HipGenotypeTable *hip = dynamic_cast<HipGenotypeTable *>(&gt);
+    if (hip && !hip->hostGTest()) {
+        // stage 2 on the device (round 4): tables, proportional fitting, measure and z for every pair in two launches
+        hip->boostGTest(passingThreshold, zval);
+        return;
+    }
+    if (hip) {
+        // (setHostGTest: round 3's form, kept as the timed baseline) the tables of all passing pairs in one device
+        // launch instead of one per pair, the fitting on this thread
         std::vector<uint> pairs;
         pairs.reserve(2 * passingThreshold.size());
         for (const SNPInteractionPair &p : passingThreshold) {

@@ -38,7 +38,7 @@ inline void to_freq(const uint *c, frequency_table &ft) {
 HipGenotypeTable::HipGenotypeTable(util::indexer *markers, util::indexer *individs, int device)
     : GenoTable(markers, individs), tbl(nullptr), device_id(device), n_individs(0), ref_words(0),
       window(1u << 16), dist_begin(0), dist_count(0), cc_begin(0), cc_count(0), mar_begin(0), prefetch(true), installed(nullptr),
-      installed_cases(0), installed_ctrls(0), check_every_call(false), calls_since_sample(0), row_cached(-1) {
+      installed_cases(0), installed_ctrls(0), check_every_call(false), calls_since_sample(0), last_cc_row(0xFFFFFFFFu), host_gtest(false), row_cached(-1) {
     installed_sample[0] = installed_sample[1] = 0;
     initialize();
 }
@@ -61,6 +61,11 @@ void HipGenotypeTable::initialize() {
     std::strcpy(gt_text[16], "00");  // err_lookup, table5.cpp:147-149
     std::cout << "Initializing HipGenotypeTable ... " << max_row << " markers x " << max_column
               << " individuals resident in HBM" << std::endl;
+    // (the reference's constructors log to cout too; this line is the one behaviour a drop-in user has to know about)
+    std::cout << "HipGenotypeTable: a CaseControlSet edited in place is recognised from its mask bytes -- all of them at "
+                 "selectCaseControl, at each new window of rows and at any getter call that is not row + 1 of the previous "
+                 "one; sampled words inside a strictly sequential walk (setMaskCheckEveryCall(true): all bytes, every call)"
+              << std::endl;
 }
 
 HipGenotypeTable::~HipGenotypeTable() {
@@ -328,8 +333,14 @@ void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControl
 
 void HipGenotypeTable::getCaseControlGenotypeDistribution(uint rIdx, CaseControlSet &ccs,
                                                           CaseControlGenotypeDistribution &ccgd) {
-    // every mask byte is compared when a new window of rows is about to be scanned, the sampled check in between
-    install(ccs, rIdx < cc_begin || rIdx >= cc_begin + cc_count);
+    // Every mask byte is compared unless this call is the strict successor of the previous one inside a scanned window
+    // (the walk of maf_func.cpp:304-314): a new window, a jump, and in particular a second walk that starts over at
+    // row 0 -- what a caller does after relabelling the same CaseControlSet in place (GeneticData::setCaseControlSet,
+    // genetic_data.cpp:115-157), also with equal group sizes -- all get the whole comparison.  Only
+    // inside a strictly sequential walk the sampled check stands in (object, counts, 32 words on every 16th call).
+    const bool sequential = rIdx == last_cc_row + 1u && rIdx >= cc_begin && rIdx < cc_begin + cc_count;
+    install(ccs, !sequential);
+    last_cc_row = rIdx;
     getCaseControlGenotypeDistribution(rIdx, ccgd);
 }
 
@@ -519,6 +530,28 @@ void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::
     });
     for (const gw_boost_hit &h : hits)
         passing.push_back(std::make_pair(std::make_pair((uint)h.snp_a, (uint)h.snp_b), h.measure));
+}
+
+void HipGenotypeTable::boostGTest(std::vector<std::pair<std::pair<uint, uint>, double> > &pairs, std::vector<double> &zval) {
+    settle();
+    if (!installed) std::abort();
+    const size_t n = pairs.size();
+    std::vector<gw_boost_hit> recs(n);
+    for (size_t k = 0; k < n; ++k) {
+        recs[k].snp_a = pairs[k].first.first;
+        recs[k].snp_b = pairs[k].first.second;
+        recs[k].measure = pairs[k].second;
+    }
+    std::vector<double> measure(n), z(n);
+    uint64_t unsettled = 0;
+    die_unless_ok(gw_boost_gtest(tbl, recs.data(), n, measure.data(), z.data(), &unsettled), "gw_boost_gtest");
+    if (unsettled)   // the reference would still be iterating (its loop has no bound)
+        std::cerr << "HipGenotypeTable: " << unsettled << " pair(s) whose proportional fitting did not settle in 2^24 sweeps"
+                  << std::endl;
+    for (size_t k = 0; k < n; ++k) {
+        pairs[k].second = measure[k];
+        zval.push_back(z[k]);
+    }
 }
 
 }  // namespace genetics

@@ -12,6 +12,8 @@
 //   --contin-debug         4x4 table of every SNP pair (epistasis_func.cpp:84-103)
 //   --epi-debug            case/control tables of every pair, all three getters
 //   --test-boost-epi       computeBoost: KSA pre-screen of all pairs + exact G test on the hits
+//   --time-boost           computeBoost phase by phase (select + margins, screen, stage 2 on the device, stage 2 on one
+//                          host thread): one JSON line
 //   --contin-perform       ContingencyPerformance timing harness
 //   --contin-cc-perform    ContingencyCCPerformance: margin-assisted case/control tables of every pair
 //   --epi-perform          EpistasisPerformance: case/control tables + two-locus LLR test of every pair
@@ -30,6 +32,7 @@
 //                              scan through the C-ABI's device form; checks the walk's counts against the batch scan;
 //                              prints one JSON line
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -54,7 +57,7 @@ static void usage() {
                  "[--scan-window ROWS] [--no-prefetch] [--mask-check-every-call] "
                  "[--world W --rank R --comm-id FILE --comm-nonce X (with --assoc or --test-boost-epi)] --time-inline-cc-maf|"
                  "--test-inline-maf|--test-inline-cc-maf|--inline-cc-maf|--select-cc-maf|--dist-perform|"
-                 "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--contin-perform|--contin-cc-perform|--epi-perform|--assoc\n";
+                 "--valid-geno|--contin-debug|--epi-debug|--margins|--test-boost-epi|--time-boost|--contin-perform|--contin-cc-perform|--epi-perform|--assoc\n";
     std::exit(2);
 }
 
@@ -219,6 +222,66 @@ int main(int argc, char **argv) {
         computeBoostSharded(&gd, shard, out);
     } else if (mode == "--test-boost-epi") {
         computeBoost(&gd, out);
+    } else if (mode == "--time-boost") {
+        // computeBoost end to end (epistasis_func.cpp:349-506), phase by phase, on the drop-in table: selectCaseControl +
+        // computeMargins, the pre-screen of all pairs, stage 2 (computeGTest) on the device -- and stage 2 once more on one
+        // host thread over device-fetched tables (round 3's form), the baseline the device form is stated against.
+        HipGenotypeTable &ht = static_cast<HipGenotypeTable &>(gt);
+        CaseControlSet &ccs = *gd.getCaseControlSet();
+        auto seconds = [](std::chrono::steady_clock::time_point t0) {
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        };
+        const int nIndivids = (int)(ccs.getCaseCount() + ccs.getControlCount());
+        double t_margins = 0, t_screen = 0, t_stage2_dev = 0, t_stage2_host = 0;
+        size_t n_hits = 0, n_over = 0;
+        double max_dev_host = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms (allocations, first launches), pass 1 is reported
+            // the masks handed over again: compaction, margins and the tiled copy are rebuilt inside the timed region
+            gw_table *h = ht.handle();
+            const uint32_t nb = gw_stream_blocks((uint32_t)gt.column_size());
+            if (gw_table_set_case_control(h, ccs.stream_case_begin(), ccs.stream_control_begin(), nb, ccs.getCaseCount(),
+                                          ccs.getControlCount()) != GW_OK) { std::cerr << gw_last_error() << std::endl; return 1; }
+            ht.tableChanged();
+            auto t0 = std::chrono::steady_clock::now();
+            gt.selectCaseControl(ccs);
+            marginal_information *pMargins = nullptr;
+            int nMarkerCount = 0;
+            computeMargins(gt, nIndivids, pMargins, nMarkerCount);
+            t_margins = seconds(t0);
+            t0 = std::chrono::steady_clock::now();
+            std::vector<SNPInteractionPair> passing;
+            ht.boostScreen(30.0, passing);
+            t_screen = seconds(t0);
+            std::vector<SNPInteractionPair> on_dev(passing), on_host(passing);
+            std::vector<double> z_dev, z_host;
+            t0 = std::chrono::steady_clock::now();
+            ht.setHostGTest(false);
+            computeGTest(gt, pMargins, (uint)nIndivids, on_dev, z_dev);
+            t_stage2_dev = seconds(t0);
+            t0 = std::chrono::steady_clock::now();
+            ht.setHostGTest(true);
+            computeGTest(gt, pMargins, (uint)nIndivids, on_host, z_host);
+            t_stage2_host = seconds(t0);
+            ht.setHostGTest(false);
+            n_hits = passing.size();
+            n_over = 0;
+            max_dev_host = 0.0;
+            for (size_t k = 0; k < n_hits; ++k) {
+                if (on_dev[k].second > 30.0) ++n_over;
+                const double dm = std::fabs(on_dev[k].second - on_host[k].second), dz = std::fabs(z_dev[k] - z_host[k]);
+                if (dm == dm && dm > max_dev_host) max_dev_host = dm;
+                if (dz == dz && dz > max_dev_host) max_dev_host = dz;
+            }
+            delete[] pMargins;
+        }
+        char line[768];
+        std::snprintf(line, sizeof line,
+                      "{\"mode\": \"time-boost\", \"n_samples\": %d, \"n_snps\": %d, \"pairs\": %.0f, \"hits_over_30\": %zu, "
+                      "\"hits_over_30_after_stage2\": %zu, \"select_and_margins_s\": %.6f, \"screen_s\": %.6f, \"stage2_device_s\": %.6f, "
+                      "\"stage2_one_host_thread_s\": %.6f, \"compute_boost_end_to_end_s\": %.6f, \"max_abs_diff_device_vs_host_stage2\": %.3g}",
+                      (int)gt.column_size(), M, 0.5 * (double)M * (double)(M - 1), n_hits, n_over, t_margins, t_screen, t_stage2_dev,
+                      t_stage2_host, t_margins + t_screen + t_stage2_dev, max_dev_host);
+        *out << line << std::endl;
     } else if (mode == "--time-inline-cc-maf") {
         // What a libgwaspp maintainer gets from the drop-in table: the reference's own harness loop walking the
         // per-row getter, served from windowed device scans -- beside the kernel rate of the same table.
@@ -338,6 +401,34 @@ int main(int argc, char **argv) {
             const bool back = row_equals(0, before, d);
             *out << (back ? "PASS" : "FAIL") << " edit seen by selectCaseControl" << std::endl;
             ok = ok && back;
+            // (3) ADVICE r03: a relabelling with EQUAL group sizes, then a second walk that starts over at row 0 of a
+            // table that fits one window (no new window, no selectCaseControl in between): the walk's first call is not
+            // row + 1 of the previous one, so every mask byte is compared and the whole walk sees the new labels --
+            // wherever in the mask the changed individuals sit
+            ht.setScanWindow(1u << 16);
+            std::set<int> cases3(cases), ctrls3(ctrls);
+            {   // swap a case and a control from the MIDDLE of the cohort (not among the sampled words' neighbours)
+                std::set<int>::const_iterator ic = cases.begin(), it = ctrls.begin();
+                std::advance(ic, (long)cases.size() / 2 + 3);
+                std::advance(it, (long)ctrls.size() / 2 + 5);
+                cases3.erase(*ic); ctrls3.erase(*it); cases3.insert(*it); ctrls3.insert(*ic);
+            }
+            std::vector<uint32_t> third;
+            if (!batch(cases3, ctrls3, third) || !batch(cases, ctrls, before)) { *out << "FAIL batch scans" << std::endl; return 3; }
+            bool walk1 = true, walk2 = true;
+            for (int i = 0; i < M; ++i) {                           // first walk, first labelling
+                gt.getCaseControlGenotypeDistribution((uint)i, ccs, d);
+                walk1 = walk1 && row_equals(i, before, d);
+            }
+            ccs.setCases(cases3);                                  // same object, same counts, other members
+            ccs.setControls(ctrls3);
+            for (int i = 0; i < M; ++i) {                           // second walk from row 0, no call in between
+                gt.getCaseControlGenotypeDistribution((uint)i, ccs, d);
+                walk2 = walk2 && row_equals(i, third, d);
+            }
+            *out << (walk1 && walk2 && third != before ? "PASS" : "FAIL")
+                 << " relabelling with equal group sizes seen by a second walk from row 0 inside one window" << std::endl;
+            ok = ok && walk1 && walk2 && third != before;
         }
         const bool differ = after != before;
         *out << (differ ? "PASS" : "FAIL") << " the two mask states give different counts" << std::endl;

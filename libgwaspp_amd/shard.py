@@ -69,3 +69,20 @@ def pair_row_blocks(n_snps: int, rank: int, world: int, block: int = 1024) -> li
             a = k * block
             out.append((a, min(block, n_snps - a)))
     return out
+
+
+def union_boost_lists(raws, capacity: int):
+    """The exchange step of the sharded pair screen seen from any rank after the all-gather: `raws` = every rank's hit
+    list as bytes (gw_boost_screen_device's layout: 32-byte header {hits, pairs, aux, aux} + capacity records).
+    -> (hits of all ranks sorted by (snp_a, snp_b), pairs evaluated by all ranks, needed_capacity, outside_model):
+    needed_capacity > capacity means some rank's list overflowed -- every rank sees the same headers, so every rank takes
+    the same decision to repeat the step with that much room (hits beyond a full list were counted, not stored);
+    outside_model != 0 means a rank's pre-filter saw a pair outside its error model (or lost candidates) and the step is
+    to be repeated with every pair in FP64 (algorithms::shardedBoostScreen does the same in C++)."""
+    import numpy as np
+    from . import capi
+    parsed = [capi.parse_boost_list(np.asarray(r, dtype=np.uint8), capacity) for r in raws]
+    needed = max([p[1] for p in parsed] + [0])
+    outside = sum(p[3] for p in parsed)
+    hits = np.concatenate([p[0] for p in parsed]) if parsed else np.zeros(0, dtype=capi.BOOST_HIT_DTYPE)
+    return np.sort(hits, order=["snp_a", "snp_b"]), sum(p[2] for p in parsed), needed, outside

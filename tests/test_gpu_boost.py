@@ -527,3 +527,114 @@ def test_fp4_counting_equals_int8_counting(n, m, missing):
         for other in ("int8", "valu"):
             assert np.array_equal(res["fp4"][0], res[other][0], equal_nan=True)
             assert np.array_equal(res["fp4"][1], res[other][1]) and res["fp4"][2:6] == res[other][2:6]
+
+
+def test_gtest_on_the_device_equals_the_oracle(oracle):
+    """gw_boost_gtest: BOOST stage 2 (computeGTest, epistasis_func.cpp:508-704) on the device against the oracle's
+    restatement, pair by pair: >= 1000 pairs of a table with missing calls, planted interactions, rare variants (tables
+    with empty cells, rows and columns) -- the IPF-fitted measure to 1e-9 relative (the device's log differs from libm's
+    in the last place), z likewise (NaN / inf where the reference divides by an empty allele class, the same on both
+    sides); every fit settles.  Then the device-list form behind a screen: {measure, z} of every hit in HBM."""
+    n, m = 3000, 96
+    rng = np.random.default_rng(42)
+    codes = _prefilter_table(rng, n, m, 0.004, True)
+    status = rng.random(n) < 0.45
+    neither = rng.random(n) < 0.05
+    for (i, j, frac) in ((1, 5, 0.6), (2, 9, 0.3), (3, 11, 0.1), (40, 77, 0.5)):
+        flip = status & (rng.random(n) < frac)
+        codes[j, flip] = codes[i, flip]
+    codes[20, :] = np.where(rng.random(n) < 0.002, 3, 1)          # nearly monomorphic rows: empty cells all over the table
+    codes[21, :] = np.where(rng.random(n) < 0.001, 2, 1)
+    codes[22, :] = 1                                               # monomorphic: two empty rows / columns
+    ts = oracle.pack_codes(codes, "stream")
+    gs = oracle.geometry_stream(n)
+    cases = np.flatnonzero(status & ~neither).astype(np.int32)
+    ctrls = np.flatnonzero(~status & ~neither).astype(np.int32)
+    _, cs, nc = oracle.ccs_masks(cases, n)
+    _, ct, nt = oracle.ccs_masks(ctrls, n)
+    n_sel = nc + nt
+    mar = []
+    for r in range(m):
+        ca, co = oracle.stream_cc_dist(ts[r], gs, cs, ct, nc, nt)
+        mar.append(oracle.marginal_information(ca, co, n_sel))
+    pairs = [(i, j) for i in range(m) for j in range(i + 1, m)]
+    sel = rng.choice(len(pairs), size=1400, replace=False)
+    must = [pairs.index(p) for p in ((1, 5), (2, 9), (3, 11), (40, 77), (20, 21), (20, 22), (21, 22), (5, 22), (0, 20))]
+    ij = np.array([pairs[k] for k in sorted(set(sel.tolist()) | set(must))], dtype=np.uint32)
+    assert ij.shape[0] >= 1000
+    pad = gs.words * 64
+    want = np.zeros((ij.shape[0], 2))
+    for k, (i, j) in enumerate(ij):
+        c16, t16 = oracle.stream_cc_contingency(ts[i], ts[j], gs, cs, ct)
+        c16[15] -= pad - nc
+        t16[15] -= pad - nt
+        want[k] = oracle.gtest(c16, t16, mar[i], mar[j], n_sel)
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        measure, z, unsettled = t.boost_gtest(ij)
+        assert unsettled == 0
+        for got, w, what in ((measure, want[:, 0], "measure"), (z, want[:, 1], "z")):
+            both_nan = np.isnan(got) & np.isnan(w)
+            same_inf = np.isinf(got) & np.isinf(w) & (np.sign(got) == np.sign(w))
+            fin = np.isfinite(got) & np.isfinite(w)
+            assert np.all(both_nan | same_inf | fin), what
+            assert fin.sum() >= 900, what
+            assert np.allclose(got[fin], w[fin], rtol=1e-9, atol=1e-9), (what, np.max(np.abs(got[fin] - w[fin])))
+        print(f"gtest: {ij.shape[0]} pairs, {int(np.isfinite(z).sum())} finite z, max |measure - oracle| "
+              f"{np.nanmax(np.abs(measure - want[:, 0])):.2e}")
+        # stage 1 + stage 2 in HBM: the screen's list, then {measure, z} per hit, nothing on the host in between
+        cap = 8192
+        lst = gw.capi.DeviceBuffer(gw.capi.BOOST_LIST_HEADER_BYTES + 16 * cap)
+        out = gw.capi.DeviceBuffer(16 * cap)
+        status_buf = gw.capi.DeviceBuffer(8)
+        s = t.stream()
+        t.boost_list_init(lst.ptr, s)
+        status_buf.memset(0, s)
+        t.boost_screen_device(0, m, 0, m, lst.ptr, cap, -1.0e9, s)  # every pair with a measure (missing calls drag it below zero: mean -44)
+        t.boost_gtest_device(lst.ptr, cap, out.ptr, status_buf.ptr, s)
+        hits, n_hits, _, aux0 = gw.parse_boost_list(lst.download(s), cap)
+        assert aux0 == 0 and 1000 <= n_hits <= cap
+        mz = out.download(s).view(np.float64).reshape(cap, 2)[:n_hits]
+        assert int(status_buf.download(s).view(np.uint64)[0]) == 0
+        m2, z2, _ = t.boost_gtest(hits)                      # the host form on the same records
+        assert np.array_equal(mz[:, 0], m2, equal_nan=True) and np.array_equal(mz[:, 1], z2, equal_nan=True)
+        assert {(1, 5), (40, 77)} <= {(int(h["snp_a"]), int(h["snp_b"])) for h in hits}
+
+
+def test_list_header_follows_the_form_the_screen_takes():
+    """gw_boost_list_init and gw_boost_screen_device take the same decision about the pre-filter (one predicate in
+    gw_capi.cpp): with it the header's slots 2 / 3 are counters that stay 0, without it (GW_OPT_BOOST_PREFILTER 0: every
+    pair in FP64) they are the ordered maximum / minimum of the measures -- the extremes gw_boost_screen reports."""
+    n, m = 4000, 300
+    cap = 1 << 14
+
+    def ordered_to_double(u):
+        u = int(u)
+        u = (u & 0x7FFFFFFFFFFFFFFF) if (u & 0x8000000000000000) else (~u & 0xFFFFFFFFFFFFFFFF)
+        return np.array([u], dtype=np.uint64).view(np.float64)[0]
+
+    with gw.GwTable(n, m) as t:
+        t.simulate(23, 0, 0, exact=True)
+        t.simulate_phenotype(23)
+        hits, nh, npairs, vmax, vmin = t.boost_screen(0, m, 0, m, threshold=12.0)
+        lst = gw.capi.DeviceBuffer(gw.capi.BOOST_LIST_HEADER_BYTES + 16 * cap)
+        s = t.stream()
+        for pre in (1, 0):
+            t.set_option(gw.capi.OPT_BOOST_PREFILTER, pre)
+            t.boost_list_init(lst.ptr, s)
+            head0 = lst.download(s)[:32].view(np.uint64).copy()
+            t.boost_screen_device(0, m, 0, m, lst.ptr, cap, 12.0, s)
+            raw = lst.download(s)
+            got, n_hits, n_pairs, aux0 = gw.parse_boost_list(raw, cap)
+            head = raw[:32].view(np.uint64)
+            assert (n_hits, n_pairs) == (nh, npairs)
+            assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(hits, order=["snp_a", "snp_b"]))
+            if pre:
+                assert t.last_boost_kernel().startswith("gw::k_boost_mfma_fp4<true")
+                assert list(head0) == [0, 0, 0, 0] and int(head[2]) == 0 and int(head[3]) == 0
+            else:
+                assert t.last_boost_kernel().startswith("gw::k_boost_mfma_fp4<false")
+                assert list(head0) == [0, 0, 0, 0xFFFFFFFFFFFFFFFF]
+                assert ordered_to_double(head[2]) == vmax and ordered_to_double(head[3]) == vmin
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)

@@ -33,7 +33,7 @@ def test_full_size_properties(oracle, cfg):
         pytest.skip(f"{cfg} needs {need / 1e9:.0f} GB of free HBM")
     first = 7_000_000  # global SNP index of row 0 (a shard in the middle of a bigger job)
     with gw.GwTable(n, m) as t:
-        t.simulate(SEED, first, 0)
+        t.simulate(SEED, first, 0, exact=True)   # the exact-count generator bench.py uses (simulate_data.cpp:191-205)
         t.simulate_phenotype(SEED)
         cs, ct, nc, nt = t.get_case_control()
         assert nc + nt == n
@@ -71,7 +71,7 @@ def test_full_size_properties(oracle, cfg):
         sample = np.unique(np.concatenate([[0, 1, m // 2, m - 2, m - 1], rng.integers(0, m, size=27)]))
         for r in sample:
             row = t.download_rows(int(r), 1)
-            want, _ = oracle.sim_table_stream(SEED, first + int(r), 1, n)
+            want, _ = oracle.sim_table_stream(SEED, first + int(r), 1, n, exact=True)
             assert np.array_equal(row, want)
             ca, co = oracle.stream_cc_dist(row[0], g, cs, ct, nc, nt)
             assert tuple(int(v) for v in counts[r]) == ca + co
@@ -130,7 +130,7 @@ def test_config5_all_pairs_of_100k_snps(oracle):
     n, m, thr = 10_000, 100_000, 30.0
     order = ["snp_a", "snp_b"]
     with gw.GwTable(n, m) as t:
-        t.simulate(SEED, 0, 0)
+        t.simulate(SEED, 0, 0, exact=True)       # bench.py's input (22 096 pairs over 30)
         t.simulate_phenotype(SEED)
         cs, ct, nc, nt = t.get_case_control()
         gs = oracle.geometry_stream(n)

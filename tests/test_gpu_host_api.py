@@ -309,4 +309,4 @@ def test_case_control_set_edited_in_place_reaches_the_device(extra):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("PASS", "FAIL"))]
     assert lines and all(ln.startswith("PASS") for ln in lines), lines
-    assert len(lines) == (2 if extra else 3)
+    assert len(lines) == (2 if extra else 4)

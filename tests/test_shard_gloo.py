@@ -116,6 +116,96 @@ def test_two_rank_gather_equals_single_process(oracle, tmp_path):
             assert np.array_equal(chunked[c][r], want)
 
 
+def _oracle_block_list(oracle, flat, m, blocks, threshold, capacity):
+    """What gw_boost_screen_device leaves in HBM for a rank's row blocks, made by the oracle: the hits of
+    [a, a + n) x [a, m) for each block appended to ONE fixed-capacity list (header: hits found, pairs evaluated, 0, 0)."""
+    from libgwaspp_amd import capi
+    iu = np.triu_indices(m, 1)
+    mine = np.zeros(len(flat), dtype=bool)
+    for a, na in blocks:
+        mine |= (iu[0] >= a) & (iu[0] < a + na)
+    hit = mine & (flat > threshold)            # NaN > threshold is false, as in the kernels
+    recs = np.zeros(int(hit.sum()), dtype=capi.BOOST_HIT_DTYPE)
+    recs["snp_a"], recs["snp_b"], recs["measure"] = iu[0][hit], iu[1][hit], flat[hit]
+    raw = np.zeros(capi.BOOST_LIST_HEADER_BYTES + 16 * capacity, dtype=np.uint8)
+    raw[:32].view(np.uint64)[:] = (len(recs), int(mine.sum()), 0, 0)
+    kept = recs[:capacity]                      # a full list counts further hits without storing them
+    raw[32:32 + 16 * len(kept)] = kept.view(np.uint8)
+    return raw
+
+
+def _pair_worker(rank, world, rdzv, m, n, seed, threshold, capacities, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from libgwaspp_amd import shard
+    from oracle import oracle
+    _init_gloo(dist, rdzv, rank, world)
+    try:
+        # every rank holds the whole table (config 5 replicates it) and screens the row blocks dealt to it
+        table, g = oracle.sim_table_stream(seed, 0, m, n)
+        cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+        flat = oracle.boost_all_pairs(table, g, cs, ct, nc, nt)
+        blocks = shard.pair_row_blocks(m, rank, world, block=16)
+        results = []
+        caps = list(capacities)                 # what every rank knows about every rank's list (attempt 0: as configured)
+        for attempt in range(3):
+            raw = _oracle_block_list(oracle, flat, m, blocks, threshold, caps[rank])
+            size = 32 + 16 * max(caps)          # the exchange is fixed-size: lists padded to the largest capacity in play
+            padded = np.zeros(size, dtype=np.uint8)
+            padded[:len(raw)] = raw
+            parts = [torch.empty(size, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(padded))
+            raws = [p.numpy()[:32 + 16 * c] for p, c in zip(parts, caps)]
+            overflow = any(int(r[:8].view(np.uint64)[0]) > c for r, c in zip(raws, caps))
+            hits, n_pairs, needed, outside = shard.union_boost_lists(raws, max(caps))
+            results.append((attempt, overflow, needed, outside, len(hits), n_pairs))
+            if not overflow:
+                break
+            caps = [needed] * world             # every rank read the same headers: the same decision everywhere
+        if rank == 0:
+            q.put((results, hits, n_pairs))
+        else:
+            q.put((results, None, None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pair_screen_union_equals_single_process(oracle, tmp_path):
+    """The config-5 step with two gloo ranks on CPU (SURVEY.md 8e "C5"; the loop sharded is epistasis_func.cpp:393-486): each
+    rank screens the row blocks shard.pair_row_blocks deals it -- the oracle stands in for the kernel -- and writes the
+    product's device-list format; the lists are all-gathered; the union parsed by capi.parse_boost_list /
+    shard.union_boost_lists must be the screen of the whole triangle.  First attempt with a capacity of 4 on rank 1: its
+    list overflows, EVERY rank sees that in the gathered headers and repeats with the room the header asks for."""
+    import torch.multiprocessing as mp
+    world, m, n, seed, threshold = 2, 60, 2000, 0x5EED, 6.0
+    table, g = oracle.sim_table_stream(seed, 0, m, n)
+    cs, ct, nc, nt = oracle.sim_phenotype_stream(seed, n)
+    flat = oracle.boost_all_pairs(table, g, cs, ct, nc, nt)
+    iu = np.triu_indices(m, 1)
+    want = flat > threshold
+    assert want.sum() > 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    rdzv = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_pair_worker, args=(r, world, rdzv, m, n, seed, threshold, [4096, 4], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    logs = [g_[0] for g_ in got]
+    assert logs[0] == logs[1]                                   # both ranks took the same decisions from the same headers
+    assert logs[0][0][1] is True and logs[0][0][2] > 4          # attempt 0: overflow seen, the header says how much room
+    assert logs[0][-1][1] is False and logs[0][-1][3] == 0      # last attempt: everything stored, error model intact
+    hits, n_pairs = next((h, p) for _, h, p in got if h is not None)
+    assert n_pairs == m * (m - 1) // 2 and len(hits) == int(want.sum())
+    assert np.array_equal(hits["snp_a"], iu[0][want]) and np.array_equal(hits["snp_b"], iu[1][want])
+    assert np.array_equal(hits["measure"], flat[want])
+
+
 def test_c_abi_shard_range_equals_the_python_partition():
     """gw_shard_range (what a C++ host uses, host-only) and shard.snp_range cut a job the same way."""
     import libgwaspp_amd as gw
