@@ -191,7 +191,7 @@ hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_
 // BOOST stage 2 on the device: computeGTest (algorithms/epistasis_func.cpp:508-704) for a list of pairs.
 //   k_gtest_tables  one wave per pair: the two 3 x 3 tables from the compacted rows (selectCaseControl's planes, so a sample
 //                   in both masks is a case only, as in the reference's compacted tables table5.cpp:989-1064)
-//   k_gtest         one lane per pair: iterative proportional fitting of the homogeneous-association model in FP64, the
+//   k_gtest         one wave per pair: iterative proportional fitting of the homogeneous-association model in FP64, the
 //                   exact interaction measure, the difference of the allelic log odds ratios over its standard error --
 //                   operation for operation the oracle's gwo_gtest (-ffp-contract=off on both sides)
 // The reference's `while (muError > 0.001)` has no bound; a kernel must have one: GTEST_MAX_ITER sweeps, after which
@@ -237,88 +237,99 @@ __global__ void __launch_bounds__(256) k_gtest_tables(const uint32_t *cc, uint64
     }
 }
 
-__global__ void __launch_bounds__(64) k_gtest(const uint32_t *tabs, const uint32_t *pairs, uint32_t pair_stride,
-                                              const unsigned long long *n_ptr, unsigned long long n_max, const SnpMargin *mar,
-                                              uint32_t n_individs, double *out, unsigned long long *status) {
+// One WAVE per pair.  The fit of a pair is a serial chain of sweeps (a table with an empty cell takes thousands of them,
+// one with missing calls millions), so what a launch takes is the slowest pair's sweep count times the latency of one
+// sweep.  Eighteen lanes share a sweep -- lane l < 18 owns cell (group l / 9, a = (l % 9) / 3, b = l % 3) -- so that a
+// sweep is 3 divisions per lane instead of 30 in one lane; the sums the reference accumulates in a fixed order (its
+// ik[], jk[] and the error it tests, 18 terms) are formed in that very order from the other lanes' values, which keeps
+// every double bit-identical to the one-lane form (the oracle's gwo_gtest; 0.0 + x = x for the first addend).
+// (a first version ran one lane per pair: config 5's 22 096 hits took 56 ms -- the slowest pair's ~20 000 sweeps at
+// 2.7 us each; this form: see DESIGN.md)
+__device__ __forceinline__ double gt_lane(double v, int src) { return __shfl(v, src, 64); }   // per-lane source: ds_bpermute
+// the same value for every lane from a lane known at compile time: two v_readlane_b32, no LDS crossbar
+__device__ __forceinline__ double gt_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint32_t *pairs, uint32_t pair_stride,
+                                               const unsigned long long *n_ptr, unsigned long long n_max, const SnpMargin *mar,
+                                               uint32_t n_individs, double *out, unsigned long long *status) {
     const unsigned long long n = n_ptr ? (*n_ptr < n_max ? *n_ptr : n_max) : n_max;
-    const unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t *ca_tab = tabs + p * 18u, *co_tab = ca_tab + 9;
-    const SnpMargin *m1 = mar + pairs[p * pair_stride], *m2 = mar + pairs[p * pair_stride + 1];
-    uint32_t f1c[3], f1t[3], f2c[3], f2t[3];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wpb = blockDim.x >> 6;
+    const int l = lane < 18 ? lane : 17;                 // lanes 18 .. 63 shadow lane 17 (their values are never read)
+    const int g = l / 9, i = l % 9, a = i / 3, b = i % 3;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * wpb + (threadIdx.x >> 6); p < n; p += (unsigned long long)gridDim.x * wpb) {
+        const uint32_t *tab = tabs + p * 18u;
+        const SnpMargin *m1 = mar + pairs[p * pair_stride], *m2 = mar + pairs[p * pair_stride + 1];
+        const uint32_t cnt = tab[9 * g + i];
+        const uint32_t tot = tab[i] + tab[9 + i];
+        const uint32_t f1 = g == 0 ? m1->cases[a] : m1->ctrls[a], f2 = g == 0 ? m2->cases[b] : m2->ctrls[b];
+        double mu = 1.0, old = 0.0;
+        double err = 18.0 * fabs(mu - old);  // :552-556 (the reference adds the first element eighteen times)
+        int iter = 0;
+        while (err > 0.001 && iter < GTEST_MAX_ITER) {
+            ++iter;
+            old = mu;
+            const double other = gt_lane(mu, g == 0 ? l + 9 : l - 9);
+            const double mij = g == 0 ? mu + other : other + mu;          // mu_ca[i] + mu_co[i]
+            mu = mij > 0 ? mu * (tot) / mij : 0.0;                        // :571-598
+            const int row = 9 * g + 3 * a, col = 9 * g + b;
+            double ik = 0.0 + gt_lane(mu, row);                           // ik[a] += mu[a][0], [a][1], [a][2] in this order
+            ik += gt_lane(mu, row + 1);
+            ik += gt_lane(mu, row + 2);
+            double jk = 0.0 + gt_lane(mu, col);                           // jk[b] += mu[0][b], [1][b], [2][b]
+            jk += gt_lane(mu, col + 3);
+            jk += gt_lane(mu, col + 6);
+            const double t1 = ik > 0 ? f1 / ik : 0.0;                     // :611-645
+            const double t3 = jk > 0 ? f2 / jk : 0.0;
+            mu = mu * (t1)*t3;
+            const double d = fabs(mu - old);
+            err = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { f1c[k] = m1->cases[k]; f1t[k] = m1->ctrls[k]; f2c[k] = m2->cases[k]; f2t[k] = m2->ctrls[k]; }
-    double mu_ca[9], mu_co[9], old_ca[9], old_co[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { mu_ca[i] = mu_co[i] = 1.0; old_ca[i] = old_co[i] = 0.0; }
-    double err = 18.0 * fabs(mu_ca[0] - old_ca[0]);  // :552-556 (the reference adds the first element eighteen times)
-    int iter = 0;
-    while (err > 0.001 && iter < GTEST_MAX_ITER) {
-        ++iter;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { old_ca[i] = mu_ca[i]; old_co[i] = mu_co[i]; }
-        double ik[6] = {0, 0, 0, 0, 0, 0}, jk[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {  // :571-598
-                const int i = 3 * a + b;
-                const uint32_t tot = ca_tab[i] + co_tab[i];
-                const double mij = mu_ca[i] + mu_co[i];
-                if (mij > 0) {
-                    mu_ca[i] = mu_ca[i] * (tot) / mij;
-                    mu_co[i] = mu_co[i] * (tot) / mij;
-                } else {
-                    mu_ca[i] = 0;
-                    mu_co[i] = 0;
-                }
-                ik[a] += mu_ca[i]; ik[3 + a] += mu_co[i];
-                jk[b] += mu_ca[i]; jk[3 + b] += mu_co[i];
-            }
-        err = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {  // :611-645
-            const double t1 = ik[a] > 0 ? f1c[a] / ik[a] : 0.0;
-            const double t2 = ik[3 + a] > 0 ? f1t[a] / ik[3 + a] : 0.0;
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int i = 3 * a + b;
-                const double t3 = jk[b] > 0 ? f2c[b] / jk[b] : 0.0;
-                const double t4 = jk[3 + b] > 0 ? f2t[b] / jk[3 + b] : 0.0;
-                mu_ca[i] = mu_ca[i] * (t1)*t3;
-                mu_co[i] = mu_co[i] * (t2)*t4;
-                err += fabs(mu_ca[i] - old_ca[i]);
-                err += fabs(mu_co[i] - old_co[i]);
+            for (int c = 0; c < 9; ++c) {                                 // err += |ca[c] - old|; err += |co[c] - old|, c = 0 .. 8
+                err += gt_bcast(d, c);
+                err += gt_bcast(d, 9 + c);
             }
         }
-    }
-    if (err > 0.001 && status) atomicAdd(&status[0], 1ull);
-    double tao = 0.0, im = 0.0;  // :648-683
+        // :648-683 -- every lane its cell's terms, lane-uniform sums in the reference's order
+        double t1 = 0.0, term1 = 0.0, term2 = 0.0, t2 = 0.0;
+        if (cnt > 0) { t1 = (double)cnt / n_individs; term1 = t1 * log(t1); }
+        const bool fitted = mu > 0;
+        if (fitted) { t2 = mu / n_individs; term2 = -t1 * log(t2); }
+        double tao = 0.0, im = 0.0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const uint32_t ca = ca_tab[i], co = co_tab[i];
-        double t1, t2;
-        if (ca > 0) { t1 = (double)ca / n_individs; im += t1 * log(t1); } else t1 = 0.0;
-        if (mu_ca[i] > 0) { t2 = mu_ca[i] / n_individs; im += -t1 * log(t2); tao += t2; }
-        if (co > 0) { t1 = (double)co / n_individs; im += t1 * log(t1); } else t1 = 0.0;
-        if (mu_co[i] > 0) { t2 = mu_co[i] / n_individs; im += -t1 * log(t2); tao += t2; }
-    }
-    out[2 * p] = (im + log(tao)) * n_individs * 2.0;
-    // allelic joint distribution and the odds-ratio z value, :686-701 (uint arithmetic, as the reference)
-    uint32_t aj[8];
+        for (int c = 0; c < 9; ++c) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const uint32_t *t = g == 0 ? ca_tab : co_tab;  // 3 x 3 here: the reference's 4 x 4 indices 0,1,2,4,5,6,8,9,10
-        aj[4 * g + 0] = (t[0] << 2) + (t[1] << 1) + (t[3] << 1) + t[4];
-        aj[4 * g + 1] = (t[2] << 2) + (t[1] << 1) + (t[5] << 1) + t[4];
-        aj[4 * g + 2] = (t[6] << 2) + (t[7] << 1) + (t[3] << 1) + t[4];
-        aj[4 * g + 3] = (t[8] << 2) + (t[7] << 1) + (t[5] << 1) + t[4];
+            for (int gg = 0; gg < 2; ++gg) {
+                const int src = 9 * gg + c;
+                const double x1 = gt_bcast(term1, src), x2 = gt_bcast(term2, src), x3 = gt_bcast(t2, src);
+                const bool has = __builtin_amdgcn_readlane((int)(cnt > 0), src) != 0, fit = __builtin_amdgcn_readlane((int)fitted, src) != 0;
+                if (has) im += x1;
+                if (fit) { im += x2; tao += x3; }
+            }
+        }
+        if (lane == 0) {
+            if (err > 0.001 && status) atomicAdd(&status[0], 1ull);
+            out[2 * p] = (im + log(tao)) * n_individs * 2.0;
+            // allelic joint distribution and the odds-ratio z value, :686-701 (uint arithmetic, as the reference)
+            uint32_t aj[8];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const uint32_t *t = tab + 9 * gg;  // 3 x 3 here: the reference's 4 x 4 indices 0,1,2,4,5,6,8,9,10
+                aj[4 * gg + 0] = (t[0] << 2) + (t[1] << 1) + (t[3] << 1) + t[4];
+                aj[4 * gg + 1] = (t[2] << 2) + (t[1] << 1) + (t[5] << 1) + t[4];
+                aj[4 * gg + 2] = (t[6] << 2) + (t[7] << 1) + (t[3] << 1) + t[4];
+                aj[4 * gg + 3] = (t[8] << 2) + (t[7] << 1) + (t[5] << 1) + t[4];
+            }
+            const double or_aff = log((double)(aj[0] * aj[3]) / (double)(aj[1] * aj[2]));
+            const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
+            const double or_unf = log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
+            const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
+            out[2 * p + 1] = (or_aff - or_unf) / sqrt(v_aff + v_unf);
+        }
     }
-    const double or_aff = log((double)(aj[0] * aj[3]) / (double)(aj[1] * aj[2]));
-    const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
-    const double or_unf = log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
-    const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
-    out[2 * p + 1] = (or_aff - or_unf) / sqrt(v_aff + v_unf);
 }
 
 hipError_t launch_boost_gtest(const uint32_t *d_cc, uint64_t cc_stride_w, uint32_t wc, uint32_t wt, const SnpMargin *d_mar,
@@ -331,7 +342,7 @@ hipError_t launch_boost_gtest(const uint32_t *d_cc, uint64_t cc_stride_w, uint32
                        d_n, n_max, d_tabs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gtest, dim3((unsigned)((n_max + 63ull) / 64ull)), dim3(64), 0, stream, d_tabs, d_pairs, pair_stride, d_n, n_max,
+    hipLaunchKernelGGL(k_gtest, dim3((waves + 3u) / 4u), dim3(256), 0, stream, d_tabs, d_pairs, pair_stride, d_n, n_max,
                        d_mar, n_individs, d_out, d_status);
     return hipGetLastError();
 }
