@@ -721,7 +721,10 @@ static hipError_t launch_scan_sub_p(const ScanArgs &args, const ScanShape &sh, h
     const int per_cu = sh.grid_blocks > 0 ? std::max(1, sh.grid_blocks / cus) : sub_resident<G, STEPS, PACK, true>();
     const int grid = cus * per_cu;
     const uint32_t total_waves = (uint32_t)grid * 4u;
-    const uint32_t f_max = std::max<uint32_t>(1u, (uint32_t)(sh.lds_cap / (size_t)per_cu) / (4u * GROUP_BYTES));
+    // (the parking area is plain dynamic LDS: at most 64 KB per workgroup -- hipFuncAttributeMaxDynamicSharedMemorySize is
+    // not raised for these instantiations -- whatever GW_OPT_BLOCKS_PER_CU leaves per workgroup)
+    const size_t per_wg = std::min<size_t>(sh.lds_cap / (size_t)per_cu, (size_t)64u << 10);
+    const uint32_t f_max = std::max<uint32_t>(1u, (uint32_t)per_wg / (4u * GROUP_BYTES));
     const uint64_t piece_rows = (uint64_t)total_waves * 64u * f_max;
     note_kernel("gw::k_scan_cc_sub<%d, %d, %s, true>", G, STEPS, tf(PACK));
     for (uint64_t r0 = 0; r0 < args.n_rows; r0 += piece_rows) {

@@ -576,6 +576,23 @@ def test_deferred_records_equal_interleaved_records(oracle, n, m, missing):
             _assert_stats(s1[r], want_s[0])
 
 
+@pytest.mark.parametrize("per_cu", [1, 2])
+def test_deferred_records_with_few_workgroups_per_cu(per_cu):
+    """GW_OPT_BLOCKS_PER_CU 1 / 2 with deferred records on the sub-wave kernels: the parking area stays within the 64 KB of
+    dynamic LDS a workgroup may ask for (the launch used to fail there), the records are the interleaved ones."""
+    n, m = 9_000, 600_000
+    with gw.GwTable(n, m) as t:
+        t.simulate(0xD1FE, 5, 0)
+        t.simulate_phenotype(0xD1FE)
+        t.set_option(capi.OPT_DEFER_RECORDS, 0)
+        c0, s0 = t.scan_case_control()
+        t.set_option(capi.OPT_BLOCKS_PER_CU, per_cu)
+        t.set_option(capi.OPT_DEFER_RECORDS, 1)
+        c1, s1 = t.scan_case_control()
+        assert t.last_scan_kernel().startswith("gw::k_scan_cc_sub<16") and t.last_scan_kernel().endswith("true>")
+        assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+
+
 def test_deferred_records_auto_policy():
     """auto: the 16-lane kernels when one call's records exceed the 256 MB Infinity Cache (3 M SNPs x 96 B)."""
     with gw.GwTable(2_000, 3_000_000) as t:
