@@ -615,21 +615,22 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     const double c_lo = std::max(g0, gp) * (1.0 + 1.0e-6), c_hi = std::max(g1, gp) * (1.0 + 1.0e-6);
     const double k0 = -(double)n * h0 - h1 * ((double)n_cases - p * (double)n);
     q.p = pf;
-    q.n48 = std::nextafter(48.0f * (float)n, INFINITY);
-    q.n30 = std::nextafter(30.0f * (float)n, INFINITY);
+    const float u = 5.9604645e-8f;  // 2^-24: the products below are exact
+    q.n48 = u * std::nextafter(48.0f * (float)n, INFINITY);
+    q.n30 = u * std::nextafter(30.0f * (float)n, INFINITY);
     q.n1 = (float)((double)n * 1.4426950408889634);
     if (std::fabs(c_hi - c_lo) <= 0.02 * std::max(c_hi, c_lo)) {  // balanced cohort: one constant, the larger (LV = 1)
         q.c_d = 0.0f;
         q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
         q.k0 = std::nextafter((float)k0, INFINITY);
-        q.c27 = 27.0f * q.c_m * 1.000001f;
+        q.c27 = u * (27.0f * q.c_m * 1.000001f);
         return q;
     }
     q.c_d = (float)(0.5 * (c_hi - c_lo));
     // c_m - c_d >= c_lo and c_m + c_d >= c_hi for the float c_d actually used
     q.c_m = std::nextafter((float)std::max(c_lo + (double)q.c_d, c_hi - (double)q.c_d), INFINITY);
     q.k0 = std::nextafter((float)k0, INFINITY);
-    q.c27 = 27.0f * (q.c_m + std::fabs(q.c_d)) * 1.000001f;
+    q.c27 = u * (27.0f * (q.c_m + std::fabs(q.c_d)) * 1.000001f);
     return q;
 }
 

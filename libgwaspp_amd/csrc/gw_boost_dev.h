@@ -201,11 +201,11 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
 //     T <= sum_c [max_a |u'_a| sum_b C_b |v'_b| + n |u_1| |v_1|] <= ea_i eb_j (SnpMarginF::ea, ::eb, rounded up).  Times N1
 //     (rounded: u) and with |tao - 1| <= T:  N1 (tao - 1) is within 8u N1 T = 11.6 u n T.
 //   * the final sum and the factor 2 ln 2 with its roundings:  u (25 c q + 13 n + 16.1 n T) + 3.5 u |bound|
-//   err below uses (27, 48, 30, 6).  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
+//   err below uses (27, 48, 30, 6), the first three folded with u into QuadBound's constants on the host.  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
 //   measure (check_upper_bound in k_boost_finish), as it checks the second level.
 struct QuadBound {
-    float p, c_m, c_d, k0, c27;  // c27 = 27 max(c_lo, c_hi); c_m == 0: no first level
-    float n48, n30;              // 48 n and 30 n (rounded up): the error bound's constant terms
+    float p, c_m, c_d, k0, c27;  // c27 = u 27 max(c_lo, c_hi), u = 2^-24; c_m == 0: no first level
+    float n48, n30;              // u 48 n and u 30 n (rounded up): the error bound's constant terms
     float n1;                    // N1 = n lg e
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
@@ -237,7 +237,8 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
     const float A0 = __builtin_fmaf(qb.c_m, q_m, qb.k0);
     const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
     const float r = 1.3862943611198906f * __builtin_fmaf(qb.n1, t1, (A1 + f1.ki) + f2.kj);  // 2 ln 2
-    err = 5.9604645e-8f * __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(6.0f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48)));
+    // (c27, n30, n48 arrive multiplied by u = 2^-24, exactly: a power of two)
+    err = __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48)));
     return r;
 }
 template <bool TWO = true>
