@@ -2,7 +2,7 @@
 # Run on the GPU box (inside one gpurun call): the rocprofv3 summaries and bench lines committed under profiles/.
 #   bash tools/collect_profiles.sh [tag]      -> gpurun_out/<tag>/...
 # The program goes directly after `--` on every rocprofv3 line (no env / bash -c hop), PMC passes carry nothing but --pmc.
-tag=${1:-r03}
+tag=${1:-r04}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp

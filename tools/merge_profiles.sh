@@ -2,7 +2,7 @@
 # Container side, after `gpurun -- bash tools/collect_profiles.sh <tag>` has merged gpurun_out/<tag>/ back:
 # stamp the PMC entries into profiles/pmc_traffic.json and copy the judged summaries into profiles/.
 #   bash tools/merge_profiles.sh [tag]
-tag=${1:-r03}
+tag=${1:-r04}
 for w in c3 c2 n10k c5; do python3 tools/collect_pmc.py merge $w $tag | tail -1; done
 for w in c3 c2 n10k c5; do
   cp gpurun_out/$tag/${w}_kernel_stats.csv profiles/${tag}_${w}_kernel_stats.csv
