@@ -826,6 +826,10 @@ def main():
                               "mfma_TOPs": rf["achieved"], "peak_TOPs": rf["peak"],
                               "frac_of_int8_peak": rf.get("frac_of_int8_peak"), "dtype": d["dtype"],
                               "cpu_baseline": d.get("cpu_baseline")})
+                    cb = d["config"].get("compute_boost")
+                    if cb:   # computeBoost end to end through the drop-in table (margins + screen + stage 2 on the device)
+                        e["compute_boost"] = cb
+                        e["compute_boost_end_to_end_ms"] = cb.get("compute_boost_end_to_end_ms")
                 return e
             extra = {"c2": side("c2", args.steps, args.warmup, False),
                      "n10k": side("n10k", args.steps, args.warmup, False),

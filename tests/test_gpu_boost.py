@@ -638,3 +638,34 @@ def test_list_header_follows_the_form_the_screen_takes():
                 assert list(head0) == [0, 0, 0, 0xFFFFFFFFFFFFFFFF]
                 assert ordered_to_double(head[2]) == vmax and ordered_to_double(head[3]) == vmin
         t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
+
+
+def test_gtest_and_candidates_edge_cases():
+    """gw_boost_gtest: no pairs, a pair outside the table, no masks; the candidate list's overflow repeat on the nine-cell
+    kernel (tables with missing calls) and on the both-groups kernel, same hits as with room."""
+    with gw.GwTable(1000, 40) as t:
+        t.simulate(3, 0, 0)
+        with pytest.raises(gw.GwError):                      # masks first (gw_table_set_case_control)
+            t.boost_gtest(np.array([[0, 1]], dtype=np.uint32))
+        t.simulate_phenotype(3)
+        m0, z0, u0 = t.boost_gtest(np.zeros((0, 2), dtype=np.uint32))
+        assert len(m0) == 0 and len(z0) == 0 and u0 == 0
+        with pytest.raises(gw.GwError):
+            t.boost_gtest(np.array([[0, 40]], dtype=np.uint32))
+        m1, z1, _ = t.boost_gtest(np.array([[0, 1], [1, 0], [5, 5]], dtype=np.uint32))   # any order, also i == j: just tables
+        assert np.isfinite(m1[0]) and m1[0] == m1[0]
+    for missing, mode, prefix in ((655, 1, "gw::k_boost_mfma_fp4<true, 3, 1, 0, false>"), (0, 2, "gw::k_boost_mfma_fp4_both<true, 0, false>")):
+        with gw.GwTable(3000, 300) as t:
+            t.simulate(31, 0, missing)
+            t.simulate_phenotype(31)
+            t.set_option(gw.capi.OPT_BOOST_MATRIX_CORES, mode)
+            exact = t.boost_measures(0, 300, 0, 300)
+            fin = np.sort(exact[np.isfinite(exact)])
+            thr = float(fin[-400])                           # ~400 pairs pass
+            want, wh, wp, _, _ = t.boost_screen(0, 300, 0, 300, threshold=thr, extremes=False)
+            assert t.last_boost_kernel() == prefix and t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
+            t.set_option(gw.capi.OPT_BOOST_CANDIDATES, 50)
+            got, gh, gp, _, _ = t.boost_screen(0, 300, 0, 300, threshold=thr, extremes=False)
+            assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 1
+            assert (gh, gp) == (wh, wp) and wh >= 399
+            assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
