@@ -13,8 +13,8 @@ That is only correct while the compiler
 A compiler bump can break any of these without a CPU-side symptom, so the Makefile runs this on the built
 object and fails the build otherwise.  Usage: check_isa.py build/gw_kernels.o
 
-Second guard (round 4), `check_isa.py --no-scratch build/gw_boost_fp4.o`: the pair kernels the default dispatch of the
-screen reaches (the pre-filtered FP4 kernels and k_boost_finish) must use NO scratch memory -- code-object metadata
+Second guard (round 4), `check_isa.py --no-scratch build/gw_boost_fp4.o` (and, with a pattern, the int8 objects): the
+pre-filtered pair kernels of every matrix-core family and k_boost_finish must use NO scratch memory -- code-object metadata
 private_segment_fixed_size == 0, no spilled VGPR / SGPR, and not one scratch_ instruction in the ISA.  Round 3's
 kernels spilled 56 - 84 bytes per lane unnoticed (3.7 GB of scratch writes per config-5 launch)."""
 import os
@@ -263,6 +263,7 @@ def main_no_scratch(obj, must_match=r"k_boost_mfma_fp4|k_boost_finish", at_least
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--no-scratch":
-        sys.exit(main_no_scratch(sys.argv[2]))
+    if sys.argv[1] == "--no-scratch":   # --no-scratch obj [regex over the mangled names] [at least this many kernels]
+        sys.exit(main_no_scratch(sys.argv[2], *(sys.argv[3:4] or [r"k_boost_mfma_fp4|k_boost_finish"]),
+                                 *([int(sys.argv[4])] if len(sys.argv) > 4 else [9])))
     sys.exit(main(sys.argv[1]))

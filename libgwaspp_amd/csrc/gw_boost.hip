@@ -669,7 +669,7 @@ hipError_t launch_boost(const BoostLaunch &l) {
     }
     if (a.cct && l.d_marf && small_case_group) {  // the same on int8 operands (exact in int32 for any cohort)
         note(fast ? "gw::k_boost_mfma_seq<%s, 2, 2, false>" : "gw::k_boost_mfma_seq<%s, 3, 1, false>", tp, "");
-        return fast ? launch_boost_mfma_seq4(a, pre, l.stream) : launch_boost_mfma_seq9(a, pre, l.stream);
+        return fast ? launch_boost_mfma_seq4(a, pre, l.compute_units, l.stream) : launch_boost_mfma_seq9(a, pre, l.compute_units, l.stream);
     }
     // tables without a missing call, case groups of any size: the FP4 kernel with both groups' accumulators in registers
     if (a.cct && l.d_marf && fast && l.fp4 && exact_in_f32) {
@@ -679,11 +679,11 @@ hipError_t launch_boost(const BoostLaunch &l) {
     }
     if (a.cct && fast) {  // any group size, 2 waves per SIMD
         note("gw::k_boost_mfma<%s>", tp, "");
-        return launch_boost_mfma_both4(a, pre, l.stream);
+        return launch_boost_mfma_both4(a, pre, l.compute_units, l.stream);
     }
     if (a.cct && l.d_marf) {  // any group size, 1 wave per SIMD
         note("gw::k_boost_mfma_seq<%s, 3, 1, true>", tp, "");
-        return launch_boost_mfma_both9(a, pre, l.stream);
+        return launch_boost_mfma_both9(a, pre, l.compute_units, l.stream);
     }
     note("gw::k_boost<%s, %s>", tfast, tp);
     return launch_boost_valu(a, fast, pre, l.stream);

@@ -331,6 +331,20 @@ __device__ __forceinline__ void boost_append_hit(const BoostArgs &a, uint32_t i,
     }
 }
 
+// a pair the in-kernel bound could not rule out leaves the kernel with its counted cells (BoostCandidateList): snp_a, snp_b,
+// cells of the cases[NP], cells of the controls[NP]; k_boost_finish<NV> takes it from there
+template <int NP>
+__device__ __forceinline__ void boost_append_candidate(const BoostArgs &a, uint32_t i, uint32_t j, const uint32_t (&cells)[2][NP]) {
+    const unsigned long long slot = atomicAdd(a.cand_count, 1ull);
+    if (slot < a.cand_cap) {
+        uint32_t *rec = a.cand + slot * (2u + 2u * NP);
+        rec[0] = i;
+        rec[1] = j;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) { rec[2 + c] = cells[0][c]; rec[2 + NP + c] = cells[1][c]; }
+    }
+}
+
 // ---- operand expansion of the int8 MFMA kernels
 constexpr int MT = 64;  // SNPs per workgroup tile side
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -360,12 +374,15 @@ __device__ __forceinline__ i32x4 expand_b(uint32_t w, uint32_t rb, int hk) {
     return v;
 }
 
-// ---- per-file launchers behind launch_boost (grid and <PRE> chosen inside)
-hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);        // gw_boost.hip
-hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_mfma.hip
-hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq4.hip
-hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, hipStream_t stream);              // gw_boost_seq9.hip
-hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, hipStream_t stream);             // gw_boost_both9.hip
+// ---- per-file launchers behind launch_boost (grid and <PRE> chosen inside).  A pre-filtered screen (pre, no dense output) of
+// any matrix-core family is: boost_screen_begin (the candidate counter zeroed), the counting kernel, launch_boost_finish
+hipError_t boost_screen_begin(const BoostArgs &a, hipStream_t stream);                            // gw_boost_fp4.hip
+hipError_t launch_boost_finish(const BoostArgs &a, bool nine, int compute_units, hipStream_t stream);
+hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_t stream);        // gw_boost.hip (everything in one kernel)
+hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);   // gw_boost_mfma.hip
+hipError_t launch_boost_mfma_seq4(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);    // gw_boost_seq4.hip
+hipError_t launch_boost_mfma_seq9(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);    // gw_boost_seq9.hip
+hipError_t launch_boost_mfma_both9(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);   // gw_boost_both9.hip
 // (the FP4 launchers enqueue k_boost_finish behind the screen when it is one with a pre-filter: compute_units sizes its grid)
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, int compute_units, hipStream_t stream);  // gw_boost_fp4*.hip
 hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream);

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_boost_finish(BoostArgs a) {
     }
 }
 
-static hipError_t finish(const BoostArgs &a, bool nine, int compute_units, hipStream_t stream) {
+hipError_t launch_boost_finish(const BoostArgs &a, bool nine, int compute_units, hipStream_t stream) {
     const dim3 grid((unsigned)(compute_units > 0 ? compute_units : 256) * 4u);
     if (nine) hipLaunchKernelGGL((k_boost_finish<3>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((k_boost_finish<2>), grid, dim3(256), 0, stream, a);
@@ -53,26 +53,26 @@ static hipError_t finish(const BoostArgs &a, bool nine, int compute_units, hipSt
 }
 
 // a screen = the candidate counter zeroed, the counting kernel, the finishing kernel, all on `stream`
-static hipError_t screen_begin(const BoostArgs &a, hipStream_t stream) {
+hipError_t boost_screen_begin(const BoostArgs &a, hipStream_t stream) {
     if (!a.cand || !a.cand_count || !a.cand_cap) return hipErrorInvalidValue;  // launch_boost's caller sizes the list
     return hipMemsetAsync(a.cand_count, 0, sizeof(unsigned long long), stream);
 }
 
 hipError_t launch_boost_mfma_fp4_both(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream) {
     if (!pre || a.dense) return launch_boost_mfma_fp4_both_full(a, pre, stream);
-    hipError_t e = screen_begin(a, stream);
+    hipError_t e = boost_screen_begin(a, stream);
     if (e != hipSuccess) return e;
     const dim3 grid = fp4_grid(a, MT);
     if (a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 2, false>), grid, dim3(256), 0, stream, a);
     else if (a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 1, false>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((k_boost_mfma_fp4_both<true, 0, false>), grid, dim3(256), 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return finish(a, false, compute_units, stream);
+    return launch_boost_finish(a, false, compute_units, stream);
 }
 
 hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, int compute_units, hipStream_t stream) {
     if (!pre || a.dense) return launch_boost_mfma_fp4_full(a, pre, nine, stream);
-    hipError_t e = screen_begin(a, stream);
+    hipError_t e = boost_screen_begin(a, stream);
     if (e != hipSuccess) return e;
     if (nine) {
         hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0, false>), fp4_grid(a, MT), dim3(256), 0, stream, a);
@@ -83,7 +83,7 @@ hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, int co
         else hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 0, false>), grid, dim3(256), 0, stream, a);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return finish(a, nine, compute_units, stream);
+    return launch_boost_finish(a, nine, compute_units, stream);
 }
 
 }  // namespace gw

@@ -205,28 +205,17 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
                 c4[g][k] = v >> 6;
             }
         const uint32_t i = i_base + (r & 3) + 8 * (r >> 2);
+        if constexpr (PRE) {  // (round 4) the pair leaves the kernel: k_boost_finish<3> runs the checks, the measure, the hit list
+            boost_append_candidate<4>(a, i, j, c4);
+            continue;
+        }
         const SnpMargin m1 = a.mar[i], m2 = *pm2;
         uint32_t ca[9], co[9];
         tables(c4, m1.cases, m1.ctrls, ca, co);
         const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
-        if (!PRE) {
-            vmax = fmax(vmax, measure);
-            vmin = fmin(vmin, measure);
-        } else if (!a.dense) {  // few pairs get here: the bound again, checked against the measure
-            float err;
-            const float bound = boost_bound(ca, co, a.marf[i], mf2, nf, inv_n, err);
-            check_bound(measure, bound, err, a.tally);
-        }
-        if (measure > a.threshold) {  // :482-484
-            const unsigned long long slot = atomicAdd(&a.tally[0], 1ull);
-            if (slot < a.max_hits) {
-                BoostHit h;
-                h.snp_a = i;
-                h.snp_b = j;
-                h.measure = measure;
-                a.hits[slot] = h;
-            }
-        }
+        vmax = fmax(vmax, measure);
+        vmin = fmin(vmin, measure);
+        if (measure > a.threshold) boost_append_hit(a, i, j, measure);  // :482-484
         if (a.dense) a.dense[(size_t)(i - a.a_begin) * a.n_b + (j - a.b_begin)] = measure;
     }
 #pragma unroll
@@ -246,11 +235,17 @@ __global__ void __launch_bounds__(256, 2) k_boost_mfma(BoostArgs a) {
     }
 }
 
-hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, hipStream_t stream) {
+hipError_t launch_boost_mfma_both4(const BoostArgs &a, bool pre, int compute_units, hipStream_t stream) {
     const dim3 grid((a.n_b + MT - 1) / MT, (a.n_a + MT - 1) / MT);
+    const bool screen = pre && !a.dense;   // candidates out, k_boost_finish behind the kernel
+    hipError_t e = screen ? boost_screen_begin(a, stream) : hipSuccess;
+    if (e != hipSuccess) return e;
     if (pre) hipLaunchKernelGGL(k_boost_mfma<true>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(k_boost_mfma<false>, grid, dim3(256), 0, stream, a);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess || !screen) return e;
+    // this kernel's bound is boost_bound (it counts four corners but evaluates all nine cells' logarithms): the finishing
+    // kernel's second level for NV = 2 is boost_bound_split -- a different bound of the same measure, checked the same way
+    return launch_boost_finish(a, false, compute_units, stream);
 }
 
 }  // namespace gw
