@@ -257,9 +257,11 @@ int gw_boost_screen(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begi
  *                        bound's error model -- must be 0, otherwise repeat with GW_OPT_BOOST_PREFILTER 0 (the host form
  *                        does that by itself); pre-filter off: the ordered maximum / minimum of the measures
  *     gw_boost_hit hits[capacity]   in no particular order
- * gw_boost_list_init zeroes the header.  gw_boost_screen_device enqueues the screen of the block on `hip_stream`
- * (NULL = the handle's stream) and does not synchronise; the first call after a mask or data change also runs
- * selectCaseControl's compaction and computeMargins (synchronous, on the handle's stream). */
+ * gw_boost_list_init zeroes the header (it needs gw_table_set_case_control: which meaning slots 2 / 3 have follows from the
+ * cohort, as in the screen itself; like the screen, the first call after a mask or data change runs selectCaseControl's
+ * compaction and computeMargins, synchronously, on the handle's stream).  gw_boost_screen_device enqueues the screen of the block
+ * on `hip_stream` (NULL = the handle's stream) and does not synchronise -- except that a call which needs a larger candidate
+ * list than any before it (GW_OPT_BOOST_CANDIDATES) re-allocates it, which waits for the device. */
 #define GW_BOOST_LIST_HEADER_BYTES 32
 int gw_boost_list_init(gw_table *t, void *d_list, void *hip_stream);
 int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, uint64_t n_b,
@@ -276,7 +278,8 @@ int gw_boost_gtest(gw_table *t, const gw_boost_hit *pairs, uint64_t n, double *m
 /* ... for a hit list in HBM as gw_boost_screen_device leaves it (header + hits; capacity as given there): the pairs are the
  * first min(n_hits, capacity) records, d_measure_z receives {measure, z} per record (2 * capacity doubles of device memory),
  * d_status (8 bytes of device memory the caller has zeroed, or NULL) is incremented per unsettled pair.  Enqueued on
- * `hip_stream` behind the screens, nothing returns to the host. */
+ * `hip_stream` behind the screens, nothing returns to the host (the first call with a larger capacity than any before it
+ * allocates its table scratch, which waits for the device). */
 int gw_boost_gtest_device(gw_table *t, const void *d_list, uint64_t capacity, void *d_measure_z, void *d_status,
                           void *hip_stream);
 /* the kernel instantiation the handle's last pair screen was dispatched to, as rocprofv3 prints it */
