@@ -409,7 +409,8 @@ typedef enum gw_option {
                                 < 65 536 (four corners, or nine cells for tables with missing calls), k_boost_mfma_fp4_both
                                 for larger case groups of tables without a missing call (cohorts < 2^24); 0 the int8
                                 forms (k_boost_mfma_seq, k_boost_mfma) */
-    GW_OPT_BOOST_FIRST_LEVEL = 19, /* pre-filtered pair screen on the FP4 four-corner kernel: 1 (default) a logarithm-free
+    GW_OPT_BOOST_FIRST_LEVEL = 19, /* pre-filtered pair screen on the FP4 kernels (four corners; since round 4 also the nine-cell
+                                form for tables with missing calls, boost_bound_quad9_f): 1 (default) a logarithm-free
                                 upper bound of the measure first (the binary entropy of every cell replaced by a quadratic
                                 that lies below it: nine v_rcp_f32, a third of the vector work; measure <= bound1 + err1,
                                 derived in gw_boost_dev.h boost_bound_quad), the bound proper only for the ~3 pairs in

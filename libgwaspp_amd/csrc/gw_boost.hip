@@ -176,6 +176,22 @@ __global__ void k_margins(const uint32_t *counts, uint32_t n_rows, uint32_t n_in
     }
     f.ea = (float)(ea * 1.000001);   // rounded up: they scale an error bound
     f.eb = (float)(eb * 1.000001);
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const double n_grp = (double)(grp == 0 ? n_cases : n_ctrls);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const uint32_t k = grp == 0 ? m.cases[g] : m.ctrls[g];
+            const double mg = (double)m.margins[g], kd = (double)k;
+            f.lqa[3 * grp + g] = k ? (float)log2(mg / kd) : 0.0f;
+            f.lqb[3 * grp + g] = k ? (float)log2(mg * n_grp / (kd * n)) : 0.0f;
+        }
+    }
+    float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ma = fmaxf(ma, fabsf(f.lqa[k])); mb = fmaxf(mb, fabsf(f.lqb[k])); }
+    f.ma = ma * 1.000001f;
+    f.mb = mb * 1.000001f;
     marf[r] = f;
 }
 
@@ -605,7 +621,7 @@ hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_
 // c_m / c_d as floats such that c_m - c_d >= c_lo and c_m + c_d >= c_hi.  c_m == 0 (no first level) for a cohort with
 // one group only.
 QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
-    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (n_cases == 0 || n_cases >= n) return q;
     const float pf = (float)((double)n_cases / (double)n);
     if (!(pf > 0.0f && pf < 1.0f)) return q;
@@ -619,6 +635,14 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     q.n48 = u * std::nextafter(48.0f * (float)n, INFINITY);
     q.n30 = u * std::nextafter(30.0f * (float)n, INFINITY);
     q.n1 = (float)((double)n * 1.4426950408889634);
+    // tables with missing calls (boost_bound_quad9_f): the linear part of the quadratic is no constant there
+    q.kx = (float)(-h1);
+    q.ks = (float)(p * h1 - h0);
+    {
+        const double big_h = 2.0 * std::fabs(h1) + 1.0;
+        q.nk = u * std::nextafter((float)((double)n * (10.0 * big_h + 26.0)), INFINITY);
+        q.n22 = u * std::nextafter(22.0f * (float)n, INFINITY);
+    }
     if (std::fabs(c_hi - c_lo) <= 0.02 * std::max(c_hi, c_lo)) {  // balanced cohort: one constant, the larger (LV = 1)
         q.c_d = 0.0f;
         q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
@@ -644,7 +668,7 @@ hipError_t launch_boost(const BoostLaunch &l) {
     a.marf = l.d_marf; a.bound_threshold = l.bound_threshold; a.dense_err = l.dense_err ? 1 : 0;
     a.cct = l.matrix_cores ? l.d_cct : nullptr;
     a.lg_n = (float)(std::log2((double)(l.n_individs ? l.n_individs : 1u)) * 1.000001) + 1.0e-5f;
-    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     a.fp4_scale[0] = 126; a.fp4_scale[1] = 127; a.fp4_scale[2] = 128;
     a.cand = l.candidates.records; a.cand_count = l.candidates.count; a.cand_cap = l.candidates.capacity;
     const bool fast = l.no_missing_call;
@@ -658,7 +682,8 @@ hipError_t launch_boost(const BoostLaunch &l) {
     const char *tp = pre ? "true" : "false", *tfast = fast ? "true" : "false";
     // the first level pays while it stops nearly every pair: it is loose by ~0.4 x a chi^2 with 8 degrees of freedom, so
     // below a threshold of ~25 more than one wave in five would run both levels (diagnostic form: whenever asked)
-    const bool first = fast && pre && l.first_level && (l.threshold >= 25.0 || l.d_dense);
+    // (tables with missing calls: the nine-cell form of the first level, on the FP4 kernel that parks its case counts)
+    const bool first = pre && l.first_level && (l.threshold >= 25.0 || l.d_dense);
     // the pair tables counted on FP4 operands (8 samples per operand dword, 64 per MFMA): four corners / nine cells,
     // one group at a time with the case counts parked in LDS as uint16
     if (a.cct && l.d_marf && small_case_group && l.fp4 && exact_in_f32) {
@@ -673,7 +698,7 @@ hipError_t launch_boost(const BoostLaunch &l) {
     }
     // tables without a missing call, case groups of any size: the FP4 kernel with both groups' accumulators in registers
     if (a.cct && l.d_marf && fast && l.fp4 && exact_in_f32) {
-        if (first) a.quad = quad_bound_constants(l.n_cases, l.n_individs);
+        if (first) a.quad = quad_bound_constants(l.n_cases, l.n_individs);  // (fast: four corners)
         note("gw::k_boost_mfma_fp4_both<%s, %s, %s>", tp, a.quad.c_m > 0.0f ? (a.quad.c_d != 0.0f ? "2" : "1") : "0");
         return launch_boost_mfma_fp4_both(a, pre, l.compute_units, l.stream);
     }

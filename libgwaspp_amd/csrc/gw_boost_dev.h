@@ -207,6 +207,7 @@ struct QuadBound {
     float p, c_m, c_d, k0, c27;  // c27 = u 27 max(c_lo, c_hi), u = 2^-24; c_m == 0: no first level
     float n48, n30;              // u 48 n and u 30 n (rounded up): the error bound's constant terms
     float n1;                    // N1 = n lg e
+    float kx, ks, nk, n22;       // tables with missing calls: -h'(p), p h'(p) - h(p); u n (10 (2 |h'(p)| + 1) + 26) and u 22 n, rounded up
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
 // TWO = false: one curvature constant for both sides (the host sets c_m = max(c_lo, c_hi), c_d = 0 -- what a balanced
@@ -240,6 +241,75 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
     // (c27, n30, n48 arrive multiplied by u = 2^-24, exactly: a power of two)
     err = __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48)));
     return r;
+}
+// The first level for tables WITH missing calls (all nine cells counted; the rows / columns of a pair's table no longer add up
+// to the SNPs' own counts).  From the measure itself (epistasis_func.cpp:424-470), with k = x (cases) / y (controls), s = x + y:
+//   measure / (2 ln 2) = sum_cells (x lg x + y lg y - s lg s) + sum_cells [x lg(qb_b qa_a / n)]_cases + [y lg(qb_b qa_a / n)]_controls + n lg tao
+// (qb = margins n_group / group of the second SNP, qa = margins / group of the first: SnpMarginF).  The middle sum is linear in
+// the cells:  sum_{a,c} Row_c[a] lqa[a,c] + sum_{b,c} Col_c[b] lqb[b,c]  with the row / column sums of the pair's counted case and
+// control tables -- twelve products (lqa = lg qa, lqb = lg(qb / n), per-SNP numbers from k_margins).  The first sum is A of the
+// no-missing form, bounded by the same quadratic,  A <= c sum d^2 / s - h(p) S - h'(p)(X - p S)  (X, S = the table's case and
+// overall totals; without missing calls that linear part was the constant k0), and  n lg tao <= N1 (tao - 1)  as there; tao from
+// all nine cells (24 multiply-adds of non-negative terms).  ~130 vector instructions + 9 v_rcp_f32 instead of boost_bound's ~375
+// with 27 v_log_f32.  Error bound, per operation (u = 2^-24; counts and their sums are exact floats below 2^24):
+//   * q as in boost_bound_quad_f:                                                                          u 16 c q
+//   * kx X + ks S: the two constants rounded (u each), two multiply-adds, |.| <= (2 |h'(p)| + 1) n =: H n:     u 4 H n
+//   * the twelve products: lq rounded (u); the row sums of a group add up to at most n, so the sum of the terms' magnitudes is at
+//     most n (M_i + M_j), M_i = max |lqa| of the first SNP, M_j = max |lqb| of the second (SnpMarginF::ma, ::mb -- ~1 - 3 for
+//     common variants, not lg n); rounded inputs + twelve accumulations: u 13 n (M_i + M_j)
+//   * tao: <= 11u relative; tao - 1 and the product with N1 (rounded): u n (15.9 + 18.8 |tao - 1|)
+//   * the sums of the three parts (2u of their magnitudes: c q + H n + n (M_i + M_j)) and the factor 2 ln 2 with its roundings:
+//   => u [25 c q + 8.4 H n + 20.8 n (M_i + M_j) + 22.1 n + 26.1 n |tao - 1|] + 3.5 u |bound|;  err below uses
+//      (27, 10 H + 26, 22, 30, 6), the constants folded with u into QuadBound::nk, ::n22, ::n30 on the host.
+template <bool TWO = true>
+__device__ __forceinline__ float boost_bound_quad9_f(const float (&fx)[9], const float (&fy)[9], const SnpMarginF &f1,
+                                                     const SnpMarginF &f2, const QuadBound &qb, float &err) {
+    float q_m = 0.0f, q_d = 0.0f, tao = 0.0f;
+    float rx[3] = {0.0f, 0.0f, 0.0f}, ry[3] = {0.0f, 0.0f, 0.0f}, cx[3] = {0.0f, 0.0f, 0.0f}, cy[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float in_c = 0.0f, in_t = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float x = fx[3 * a + b], y = fy[3 * a + b], s = x + y;
+            const float d = __builtin_fmaf(-qb.p, s, x);
+            const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
+            q_m = __builtin_fmaf(d, t, q_m);
+            if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
+            rx[a] += x; ry[a] += y; cx[b] += x; cy[b] += y;   // exact
+            in_c = __builtin_fmaf(s, f2.rb[b], in_c);
+            in_t = __builtin_fmaf(s, f2.rb[3 + b], in_t);
+        }
+        tao = __builtin_fmaf(f1.pa[a], in_c, tao);
+        tao = __builtin_fmaf(f1.pa[3 + a], in_t, tao);
+    }
+    const float xs = (rx[0] + rx[1]) + rx[2], ss = xs + ((ry[0] + ry[1]) + ry[2]);  // exact
+    float k = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        k = __builtin_fmaf(rx[g], f1.lqa[g], k);
+        k = __builtin_fmaf(ry[g], f1.lqa[3 + g], k);
+        k = __builtin_fmaf(cx[g], f2.lqb[g], k);
+        k = __builtin_fmaf(cy[g], f2.lqb[3 + g], k);
+    }
+    const float t1 = tao - 1.0f;
+    const float lin = __builtin_fmaf(qb.kx, xs, qb.ks * ss);
+    const float A0 = __builtin_fmaf(qb.c_m, q_m, lin);
+    const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
+    const float r = 1.3862943611198906f * __builtin_fmaf(qb.n1, t1, A1 + k);  // 2 ln 2
+    err = __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, fabsf(t1), __builtin_fmaf(qb.n22, f1.ma + f2.mb, qb.nk))));
+    return r;
+}
+template <bool TWO = true>
+__device__ __forceinline__ float boost_bound_quad9(const uint32_t (&ca)[9], const uint32_t (&co)[9], const SnpMarginF &f1,
+                                                   const SnpMarginF &f2, const QuadBound &qb, float &err) {
+    float fx[9], fy[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        fx[c] = (float)ca[c];
+        fy[c] = (float)co[c];
+    }
+    return boost_bound_quad9_f<TWO>(fx, fy, f1, f2, qb, err);
 }
 template <bool TWO = true>
 __device__ __forceinline__ float boost_bound_quad(const uint32_t (&ca)[9], const uint32_t (&co)[9],

@@ -36,9 +36,13 @@ __global__ void __launch_bounds__(256) k_boost_finish(BoostArgs a) {
         const double measure = boost_measure(ca, co, m1, m2, a.n_individs, a.frac, a.xlogx);
         check_bound(measure, bound2, err2, a.tally);
         if (first_level) {
-            float err1;
-            const float bound1 = a.quad.c_d != 0.0f ? boost_bound_quad<true>(ca, co, f1, f2, nf, a.quad, err1)
-                                                    : boost_bound_quad<false>(ca, co, f1, f2, nf, a.quad, err1);
+            float err1, bound1;
+            if constexpr (NV == 2)
+                bound1 = a.quad.c_d != 0.0f ? boost_bound_quad<true>(ca, co, f1, f2, nf, a.quad, err1)
+                                            : boost_bound_quad<false>(ca, co, f1, f2, nf, a.quad, err1);
+            else
+                bound1 = a.quad.c_d != 0.0f ? boost_bound_quad9<true>(ca, co, f1, f2, a.quad, err1)
+                                            : boost_bound_quad9<false>(ca, co, f1, f2, a.quad, err1);
             check_upper_bound(measure, bound1, err1, a.tally);
         }
         if (measure > a.threshold) boost_append_hit(a, i, j, measure);
@@ -75,7 +79,10 @@ hipError_t launch_boost_mfma_fp4(const BoostArgs &a, bool pre, bool nine, int co
     hipError_t e = boost_screen_begin(a, stream);
     if (e != hipSuccess) return e;
     if (nine) {
-        hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0, false>), fp4_grid(a, MT), dim3(256), 0, stream, a);
+        const dim3 grid = fp4_grid(a, MT);
+        if (a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 2, false>), grid, dim3(256), 0, stream, a);
+        else if (a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 1, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0, false>), grid, dim3(256), 0, stream, a);
     } else {
         const dim3 grid = fp4_grid(a, 2 * MT);
         if (a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 2, 2, 2, false>), grid, dim3(256), 0, stream, a);

@@ -25,7 +25,9 @@ hipError_t launch_boost_mfma_fp4_full(const BoostArgs &a, bool pre, bool nine, h
     if (pre && !a.dense) return hipErrorInvalidValue;
     if (nine) {
         const dim3 grid = fp4_grid(a, MT);
-        if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0, true>), grid, dim3(256), 0, stream, a);
+        if (pre && a.quad.c_m > 0.0f && a.quad.c_d != 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 2, true>), grid, dim3(256), 0, stream, a);
+        else if (pre && a.quad.c_m > 0.0f) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 1, true>), grid, dim3(256), 0, stream, a);
+        else if (pre) hipLaunchKernelGGL((k_boost_mfma_fp4<true, 3, 1, 0, true>), grid, dim3(256), 0, stream, a);
         else if (a.dense) hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, 0, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_boost_mfma_fp4<false, 3, 1, 0, false>), grid, dim3(256), 0, stream, a);
     } else {

@@ -127,6 +127,11 @@ struct SnpMarginF {
     //   (C_g = everyone with genotype g): ea x eb bounds the sum of the magnitudes of the terms tao - 1 is made of
     float ea, eb;
     float ua[6], vb[6];
+    // round 4, tables WITH missing calls (boost_bound_quad9_f): lqa[3 c + g] = log2(qa[3 c + g]), lqb[3 c + g] = log2(qb[3 c + g] / n),
+    // 0 where the count is 0 -- the pair's sum_cells k log2(qb qa / n) is then twelve products with the row / column sums of
+    // its counted tables
+    float lqa[6], lqb[6];
+    float ma, mb;   // max |lqa[.]|, max |lqb[.]|, rounded up: they scale the rounding error of those twelve products
 };
 struct BoostHit {  // == gw_boost_hit of include/gwas_scan.h
     uint32_t snp_a, snp_b;

@@ -438,7 +438,9 @@ def test_block_calls_on_fp4_equal_the_int8_kernels(n, m):
     with gw.GwTable(2000, 100) as t:    # a table with missing calls: nine cells
         t.simulate(11, 3, 655)
         t.simulate_phenotype(11)
-        t.boost_screen(0, 100, 0, 100, extremes=False)
+        t.boost_screen(0, 100, 0, 100, extremes=False)      # threshold 30: the nine-cell first level
+        assert t.last_boost_kernel() in ("gw::k_boost_mfma_fp4<true, 3, 1, 1, false>", "gw::k_boost_mfma_fp4<true, 3, 1, 2, false>")
+        t.boost_screen(0, 100, 0, 100, threshold=8.0, extremes=False)
         assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0, false>"
 
 
@@ -662,6 +664,7 @@ def test_gtest_and_candidates_edge_cases():
             exact = t.boost_measures(0, 300, 0, 300)
             fin = np.sort(exact[np.isfinite(exact)])
             thr = float(fin[-400])                           # ~400 pairs pass
+            assert thr < 25.0                                 # (below 25 the screen runs without the first level)
             want, wh, wp, _, _ = t.boost_screen(0, 300, 0, 300, threshold=thr, extremes=False)
             assert t.last_boost_kernel() == prefix and t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
             t.set_option(gw.capi.OPT_BOOST_CANDIDATES, 50)
@@ -669,3 +672,83 @@ def test_gtest_and_candidates_edge_cases():
             assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 1
             assert (gh, gp) == (wh, wp) and wh >= 399
             assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
+
+
+@pytest.mark.parametrize("n,m,case_share,p_missing,neither", [(800, 40, 0.5, 0.01, 0.0), (6000, 56, 0.45, 0.01, 0.05),
+                                                              (6000, 40, 0.2, 0.03, 0.0), (40_000, 36, 0.6, 0.005, 0.1)])
+def test_first_level_bound_for_tables_with_missing_calls(oracle, n, m, case_share, p_missing, neither):
+    """The nine-cell form of the first level (gw_boost_dev.h boost_bound_quad9_f, k_boost_mfma_fp4<true, 3, 1, 1 or 2>): for every
+    pair measure <= bound1 + err1; the device's value lies within err1 of the same formula in FP64 from the pair's counted cells
+    (the quadratic under the entropy, the twelve row / column-sum products, n lg e (tao - 1)); and the hit lists with the first
+    level on, off and without any pre-filter are the same for thresholds on and just below pair measures."""
+    rng = np.random.default_rng(17 * n + m)
+    codes = _prefilter_table(rng, n, m, p_missing, False)
+    u = rng.random(n)
+    is_case = u < case_share * (1.0 - neither)
+    is_ctrl = (u >= case_share * (1.0 - neither)) & (u < 1.0 - neither)
+    for (i, j, frac) in ((1, 5, 0.95), (2, 9, 0.8), (3, 11, 0.6), (4, 13, 0.4)):     # strong ones: missing calls drag the measure down
+        flip = is_case & (rng.random(n) < frac)
+        codes[j, flip] = codes[i, flip]
+    ts = oracle.pack_codes(codes, "stream")
+    _, cs, nc = oracle.ccs_masks(np.flatnonzero(is_case).astype(np.int32), n)
+    _, ct, nt = oracle.ccs_masks(np.flatnonzero(is_ctrl).astype(np.int32), n)
+    n_sel = nc + nt
+    p, c_lo, c_hi, _, level = _quad_constants(nc, n_sel)
+    h0 = -(p * np.log2(p) + (1 - p) * np.log2(1 - p))
+    h1 = np.log2((1 - p) / p)
+    ind = lambda grp, k: (codes[:, grp] == k).astype(np.float32)
+    X = np.array([[ind(is_case, a) @ ind(is_case, b).T for b in (1, 2, 3)] for a in (1, 2, 3)], dtype=np.float64)
+    Y = np.array([[ind(is_ctrl, a) @ ind(is_ctrl, b).T for b in (1, 2, 3)] for a in (1, 2, 3)], dtype=np.float64)
+    S = X + Y
+    xlgx = lambda v: np.where(v > 0, v * np.log2(np.maximum(v, 1.0)), 0.0)
+    A = (xlgx(X) + xlgx(Y) - xlgx(S)).sum(axis=(0, 1))
+    D = X - p * S
+    quad = (np.where(D < 0, c_lo, c_hi) * np.where(S > 0, D ** 2 / np.maximum(S, 1.0), 0.0)).sum(axis=(0, 1))
+    A1 = quad - h0 * S.sum(axis=(0, 1)) - h1 * (X.sum(axis=(0, 1)) - p * S.sum(axis=(0, 1)))
+    assert np.all(A <= A1 + 1e-6)                       # the inequality itself, in FP64
+    # the SNPs' own counts (over every selected individual, also those missing at the other SNP) and tao
+    cnt = lambda grp: np.array([(codes[:, grp] == k).sum(axis=1) for k in (1, 2, 3)], dtype=np.float64)   # 3, m
+    xc, yc = cnt(is_case), cnt(is_ctrl)
+    mg = xc + yc
+    tao = np.zeros((m, m))
+    for G, n_g in ((xc, float(nc)), (yc, float(nt))):
+        for ka in range(3):
+            for kb in range(3):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tao += np.nan_to_num(S[ka, kb] * G[ka][:, None] * G[kb][None, :] / (mg[ka][:, None] * mg[kb][None, :] * n_g))
+    lin_slack = 2.0 * n_sel * (tao - 1.0 - np.log(tao))
+    with gw.GwTable(n, m) as t:
+        t.upload_rows(0, ts)
+        t.set_case_control(cs, ct, nc, nt)
+        exact = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 4)
+        b1 = t.boost_measures(0, m, 0, m)
+        assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 3, 1, {level}, true>"
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 5)
+        e1 = t.boost_measures(0, m, 0, m)
+        t.set_option(gw.capi.OPT_BOOST_PREFILTER, 1)
+        iu = np.triu_indices(m, 1)
+        ex, bb, ee = exact[iu], b1[iu], e1[iu]
+        want = ex + 2.0 * np.log(2.0) * (A1 - A)[iu] + lin_slack[iu]      # the same formula in FP64
+        ok = np.isfinite(ex) & np.isfinite(bb) & np.isfinite(ee) & np.isfinite(want)
+        assert ok.sum() >= 0.9 * np.isfinite(ex).sum()
+        dev = np.abs(bb[ok] - want[ok])
+        assert np.all(ex[ok] <= bb[ok] + ee[ok])
+        assert np.all(dev <= ee[ok]), (dev.max(), (dev / ee[ok]).max())
+        print(f"n={n_sel} p={p:.3f} missing {p_missing}: max |bound1 - formula| / err1 = {(dev / ee[ok]).max():.3f}, median err1 = {np.median(ee[ok]):.4f}, "
+              f"median slack = {np.median(bb[ok] - ex[ok]):.2f}, first level reaches 30 for {np.mean(bb[ok] + ee[ok] >= 30.0):.4f} of the pairs")
+        finite = np.sort(ex[np.isfinite(ex)])
+        high = finite[finite >= 25.0]
+        assert len(high) >= 1
+        thresholds = [30.0, 25.0, float(finite[-1]), float(finite[-2]), 1.0e9] + [float(v) for v in high[:3]]
+        thresholds += [float(np.nextafter(v, -np.inf)) for v in high[:2]]
+        for thr in thresholds:
+            ref_hits, ref_n, ref_pairs, _, _ = t.boost_screen(0, m, 0, m, threshold=thr)           # all FP64
+            for first in (1, 0):
+                t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, first)
+                hits, n_hits, n_pairs, *_ = t.boost_screen(0, m, 0, m, threshold=thr, extremes=False)
+                assert t.last_boost_kernel() == f"gw::k_boost_mfma_fp4<true, 3, 1, {level if first else 0}, false>"
+                assert (n_hits, n_pairs) == (ref_n, ref_pairs)
+                assert np.array_equal(np.sort(hits, order=["snp_a", "snp_b"]), np.sort(ref_hits, order=["snp_a", "snp_b"]))
+        t.set_option(gw.capi.OPT_BOOST_FIRST_LEVEL, 1)
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0     # neither level's run-time check fired
