@@ -10,6 +10,8 @@
 //   bit 5  the refills addressed as uniform base (SGPR pair) + per-lane 32-bit offset instead of per-lane 64-bit pointers
 //   bit 6  only the B row is refilled (2 of the 6 loads per 32 MFMAs), bit 7  only the A rows (4 of 6)
 //   bit 8  the refills as dwordx2 loads (twice as many instructions, the same bytes)
+//   bit 9  with bit 7: the B row comes from LDS (ds_read_b128 of a static buffer) instead of global memory -- what sharing
+//          operand rows between the waves of a workgroup through LDS would turn a third of the refills into
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_loop_probe tools/mfma_loop_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -30,7 +32,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, int rounds, int sc_half, int sc_one, int sc_two,
                                                 uint32_t chunk_mask) {
-    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16, SADDR = MODE & 32, ONLY_B = MODE & 64, ONLY_A = MODE & 128, X2 = MODE & 256;
+    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16, SADDR = MODE & 32, ONLY_B = MODE & 64, ONLY_A = MODE & 128, X2 = MODE & 256, B_LDS = MODE & 512;
+    __shared__ u32x4 s_b[B_LDS ? 256 * 4 : 1];
+    if (B_LDS) { for (int k = 0; k < 4; ++k) s_b[k * 256 + threadIdx.x] = tbl[k * 256 + threadIdx.x]; __syncthreads(); }
     constexpr int TA = 2, NV = 2, NP = 4, NT = 8, RING = 4;
     const uint32_t t = threadIdx.x, lane = t & 63u, fr = lane & 31u, fh = lane >> 5, wave = t >> 6;
     const u32x4 *ga[TA], *gb;
@@ -124,6 +128,7 @@ __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, i
                     } else {
                         if (!ONLY_B) for (int ta = 0; ta < TA; ++ta) ua[k + d][ta] = ga[ta][nxt];
                         if (!ONLY_A) ub[k + d] = gb[nxt];
+                        if (B_LDS) ub[k + d] = s_b[((c0 + k + d) & 3u) * 256u + threadIdx.x];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -178,6 +183,7 @@ int main() {
         run<7 + 64>("the kernel's loop without the pattern, 2 of the 6 refills", dtbl, dout, w, cus);
         run<7 + 128>("the kernel's loop without the pattern, 4 of the 6 refills", dtbl, dout, w, cus);
         run<7 + 256>("the kernel's loop without the pattern, refills as 12 dwordx2 loads", dtbl, dout, w, cus);
+        run<7 + 128 + 512>("the kernel's loop without the pattern, 4 of the 6 refills + the B row from LDS", dtbl, dout, w, cus);
     }
     return 0;
 }
