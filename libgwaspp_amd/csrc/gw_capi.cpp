@@ -1102,7 +1102,9 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     // large call (a dense block of 20 k x 20 k measures is 3.2 GB) must not sit next to a 125 GB table for ever
     const size_t keep = (size_t)256u << 20;
     if (t->dense_buf_bytes > keep) { (void)hipFree(t->d_dense_buf); t->d_dense_buf = nullptr; t->dense_buf_bytes = 0; }
-    if (t->cand_bytes > keep) { (void)hipFree(t->d_cand); t->d_cand = nullptr; t->cand_bytes = 0; }
+    // (the candidate list of a whole-triangle screen is 1.3 GB at its 32 M-record cap -- next to the 0.25 - 3 GB tables that
+    // get pair screens; allocating and freeing it around every call cost a computeBoost ~5 ms of its ~85)
+    if (t->cand_bytes > 8u * keep) { (void)hipFree(t->d_cand); t->d_cand = nullptr; t->cand_bytes = 0; }
     if (t->hits_buf_bytes > keep) { (void)hipFree(t->d_hits_buf); t->d_hits_buf = nullptr; t->hits_buf_bytes = 0; }
     return GW_OK;
 }
