@@ -28,53 +28,74 @@
 
 namespace gw {
 // ---------------------------------------------------------------------------
-// selectCaseControl: gather the members' bits into dense planes.
-// src_idx[k] = sample index of the k-th member (cases first: [0, n_case), then
-// controls: [case_pad_bits, case_pad_bits + n_ctrl)); 0xFFFFFFFF = pad bit.
-// One workgroup per SNP row, the row's two planes staged in LDS.
-// Compact row layout (32-bit words): [case p0 | case p1 | ctrl p0 | ctrl p1],
-// case planes wc words, control planes wt words.
+// selectCaseControl: the members' bits of a row gathered into dense planes (compressed_genotype_table5.cpp:443-575 does it
+// bit by bit; so did this kernel until round 4, one output bit at a time through an index list: 2.0 ms for 100 000 rows x
+// 10 000 samples).  Now word by word: a 32-sample word of a plane is compressed under the group's mask word by the
+// five-stage network of "Hacker's Delight" 7-4 (the masks are the same for every row: the host prepares the network once
+// per mask, `plan`), and the compressed bits are OR-ed into the row's output at the bit offset of the word's first member
+// (LDS atomics: a word's bits land in at most two output words).
+// plan: four u32x4 per input word -- {case mask, mv0, mv1, mv2} {mv3, mv4, bit offset, members} and the same for controls.
+// Compact row layout (32-bit words): [case p0 | case p1 | ctrl p0 | ctrl p1], case planes wc words, control planes wt words.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_select_cc(const u32x4 *table, uint64_t row_stride_u,
-                                                   uint32_t plane_stride_u, uint32_t units, uint32_t n_rows,
-                                                   const uint32_t *src_idx, uint32_t wc, uint32_t wt,
-                                                   uint32_t *cc, uint64_t cc_stride_w) {
-    extern __shared__ uint32_t s_row[];  // [2][units*4]
-    const uint32_t words = units * 4u;
-    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+__device__ __forceinline__ uint32_t compress_bits(uint32_t x, const u32x4 &a, const u32x4 &b) {
+    x &= a[0];
+    uint32_t t;
+    t = x & a[1]; x = (x ^ t) | (t >> 1);
+    t = x & a[2]; x = (x ^ t) | (t >> 2);
+    t = x & a[3]; x = (x ^ t) | (t >> 4);
+    t = x & b[0]; x = (x ^ t) | (t >> 8);
+    t = x & b[1]; x = (x ^ t) | (t >> 16);
+    return x;
+}
+__device__ __forceinline__ void place_bits(uint32_t *plane, uint32_t bits, uint32_t off, uint32_t count) {
+    const uint32_t sh = off & 31u;
+    if (bits) atomicOr(&plane[off >> 5], bits << sh);
+    if (sh + count > 32u && (bits >> (32u - sh))) atomicOr(&plane[(off >> 5) + 1u], bits >> (32u - sh));
+}
+__global__ void __launch_bounds__(256) k_select_cc(const u32x4 *table, uint64_t row_stride_u, uint32_t plane_stride_u,
+                                                   uint32_t n_words, uint32_t n_rows, const u32x4 *plan, uint32_t wc,
+                                                   uint32_t wt, uint32_t *cc, uint64_t cc_stride_w) {
+    extern __shared__ uint32_t s_out[];  // one compact row
+    const uint32_t total = 2u * (wc + wt);
+    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) s_out[k] = 0u;
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {  // (the same trip count for every thread of a workgroup)
         const uint32_t *p0 = reinterpret_cast<const uint32_t *>(table + (uint64_t)r * row_stride_u);
         const uint32_t *p1 = p0 + (uint64_t)plane_stride_u * 4u;
         __syncthreads();
-        for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) {
-            s_row[w] = p0[w];
-            s_row[words + w] = p1[w];
+        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) {
+            const uint32_t x0 = p0[w], x1 = p1[w];
+            const u32x4 ca = plan[4u * w], cb = plan[4u * w + 1u], ta = plan[4u * w + 2u], tb = plan[4u * w + 3u];
+            if (cb[3]) {
+                place_bits(s_out, compress_bits(x0, ca, cb), cb[2], cb[3]);
+                place_bits(s_out + wc, compress_bits(x1, ca, cb), cb[2], cb[3]);
+            }
+            if (tb[3]) {
+                place_bits(s_out + 2u * wc, compress_bits(x0, ta, tb), tb[2], tb[3]);
+                place_bits(s_out + 2u * wc + wt, compress_bits(x1, ta, tb), tb[2], tb[3]);
+            }
         }
         __syncthreads();
         uint32_t *out = cc + (uint64_t)r * cc_stride_w;
-        const uint32_t total = wc + wt;  // output words per plane
         for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
-            uint32_t lo = 0, hi = 0;
-#pragma unroll 8
-            for (uint32_t b = 0; b < 32u; ++b) {
-                const uint32_t s = src_idx[k * 32u + b];
-                if (s != 0xFFFFFFFFu) {
-                    lo |= ((s_row[s >> 5] >> (s & 31u)) & 1u) << b;
-                    hi |= ((s_row[words + (s >> 5)] >> (s & 31u)) & 1u) << b;
-                }
-            }
-            if (k < wc) { out[k] = lo; out[wc + k] = hi; }
-            else { out[2u * wc + (k - wc)] = lo; out[2u * wc + wt + (k - wc)] = hi; }
+            out[k] = s_out[k];
+            s_out[k] = 0u;  // for the next row (the barrier at the top orders it before that row's atomics)
         }
     }
 }
 
-hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
-                            uint32_t *d_cc, uint64_t cc_stride_w, hipStream_t stream) {
+hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_plan, uint32_t n_words, uint32_t wc, uint32_t wt,
+                            uint32_t *d_cc, uint64_t cc_stride_w, int compute_units, hipStream_t stream) {
     if (tv.n_snps == 0) return hipSuccess;
-    const uint32_t grid = (uint32_t)(tv.n_snps < 8192 ? tv.n_snps : 8192);
-    hipLaunchKernelGGL(k_select_cc, dim3(grid), dim3(256), (size_t)tv.units * 32u, stream, tv.base,
-                       tv.row_stride_u, tv.plane_stride_u, tv.units, (uint32_t)tv.n_snps, d_src_idx, wc, wt,
-                       d_cc, cc_stride_w);
+    const size_t lds = (size_t)2u * (wc + wt) * sizeof(uint32_t);
+    if (lds > (size_t)160u * 1024u - 256u) return hipErrorInvalidValue;  // a compact row has to fit the 160 KB of a CU's LDS
+    if (lds > 48u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_cc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint64_t cap = (uint64_t)(compute_units > 0 ? compute_units : 256) * 8u;
+    const uint32_t grid = (uint32_t)(tv.n_snps < cap ? tv.n_snps : cap);
+    hipLaunchKernelGGL(k_select_cc, dim3(grid), dim3(256), lds, stream, tv.base, tv.row_stride_u, tv.plane_stride_u,
+                       n_words, (uint32_t)tv.n_snps, reinterpret_cast<const u32x4 *>(d_plan), wc, wt, d_cc, cc_stride_w);
     return hipGetLastError();
 }
 

@@ -878,9 +878,31 @@ int ensure_selected(gw_table *t) {
     // with unconditional 16-byte loads
     const uint32_t wc = std::max<uint32_t>(32u, (uint32_t)((cases.size() + 1023u) / 1024u) * 32u);
     const uint32_t wt = std::max<uint32_t>(32u, (uint32_t)((ctrls.size() + 1023u) / 1024u) * 32u);
-    std::vector<uint32_t> src((size_t)(wc + wt) * 32u, 0xFFFFFFFFu);
-    std::copy(cases.begin(), cases.end(), src.begin());
-    std::copy(ctrls.begin(), ctrls.end(), src.begin() + (size_t)wc * 32u);
+    // the compaction plan: per 32-sample word of a row and per group, the mask word with its compress network
+    // ("Hacker's Delight" 7-4), the bit offset of its first member in the group's dense planes, its member count
+    const uint32_t n_words = (t->geo.n_samples + 31u) / 32u;
+    std::vector<uint32_t> src((size_t)n_words * 16u, 0u);
+    for (int g = 0; g < 2; ++g) {
+        const std::vector<uint32_t> &members = g == 0 ? cases : ctrls;
+        for (uint32_t s : members) src[(size_t)(s >> 5) * 16u + 8u * g] |= 1u << (s & 31u);
+        uint32_t offset = 0;
+        for (uint32_t w = 0; w < n_words; ++w) {
+            uint32_t *rec = &src[(size_t)w * 16u + 8u * g];
+            uint32_t mask = rec[0], mk = ~mask << 1;
+            for (int i = 0; i < 5; ++i) {
+                uint32_t mp = mk ^ (mk << 1);
+                mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+                const uint32_t mv = mp & mask;
+                rec[1 + i] = mv;
+                mask = (mask ^ mv) | (mv >> (1u << i));
+                mk &= ~mp;
+            }
+            const uint32_t count = (uint32_t)__builtin_popcount(rec[0]);
+            rec[6] = offset;
+            rec[7] = count;
+            offset += count;
+        }
+    }
     const uint64_t stride_w = 2ull * (wc + wt);
     // the compacted planes and their tiled copy depend on the group sizes: kept while those stay the same (new
     // masks of the same cohort -- another phenotype -- re-use them); the per-SNP margins never change size
@@ -899,7 +921,7 @@ int ensure_selected(gw_table *t) {
     uint32_t *d_src = nullptr;
     GW_HIP(hipMalloc((void **)&d_src, src.size() * sizeof(uint32_t)));
     hipError_t e = hipMemcpyAsync(d_src, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream);
-    if (e == hipSuccess) e = gw::launch_select_cc(t->tv, d_src, wc, wt, t->d_cc, stride_w, t->stream);
+    if (e == hipSuccess) e = gw::launch_select_cc(t->tv, d_src, n_words, wc, wt, t->d_cc, stride_w, t->compute_units, t->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     (void)hipFree(d_src);
     if (e != hipSuccess) {

@@ -149,8 +149,10 @@ struct BoostCandidateList {
 inline size_t boost_candidate_bytes(bool nine_cells) { return (2u + 2u * (nine_cells ? 9u : 4u)) * sizeof(uint32_t); }
 
 // selectCaseControl compaction (table5.cpp:443-575) of the whole table
-hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_src_idx, uint32_t wc, uint32_t wt,
-                            uint32_t *d_cc, uint64_t cc_stride_w, hipStream_t stream);
+// d_plan: 16 uint32 per 32-sample word of a row (n_words of them) -- per group the mask word, the five masks of its
+// compress network, the bit offset of the word's first member in the group's planes and its member count (gw_boost.hip)
+hipError_t launch_select_cc(const TableView &tv, const uint32_t *d_plan, uint32_t n_words, uint32_t wc, uint32_t wt,
+                            uint32_t *d_cc, uint64_t cc_stride_w, int compute_units, hipStream_t stream);
 hipError_t launch_margins(const uint32_t *d_counts, uint32_t n_rows, uint32_t n_individs, SnpMargin *d_mar,
                           SnpMarginF *d_marf, hipStream_t stream);
 // BOOST pre-screen of the SNP block pair [a_begin,+n_a) x [b_begin,+n_b), pairs i < j
