@@ -303,12 +303,8 @@ __global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint3
         const uint32_t cnt = tab[9 * g + i];
         const uint32_t tot = tab[i] + tab[9 + i];
         const uint32_t f1 = g == 0 ? m1->cases[a] : m1->ctrls[a], f2 = g == 0 ? m2->cases[b] : m2->ctrls[b];
-        double mu = 1.0, old = 0.0;
-        double err = 18.0 * fabs(mu - old);  // :552-556 (the reference adds the first element eighteen times)
-        int iter = 0;
-        while (err > 0.001 && iter < GTEST_MAX_ITER) {
-            ++iter;
-            old = mu;
+        // One sweep of the fit (:571-645): every lane its cell, sums in the reference's order.
+        auto sweep = [&](double mu) -> double {
             const double other = gt_lane(mu, g == 0 ? l + 9 : l - 9);
             const double mij = g == 0 ? mu + other : other + mu;          // mu_ca[i] + mu_co[i]
             mu = mij > 0 ? mu * (tot) / mij : 0.0;                        // :571-598
@@ -321,14 +317,27 @@ __global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint3
             jk += gt_lane(mu, col + 6);
             const double t1 = ik > 0 ? f1 / ik : 0.0;                     // :611-645
             const double t3 = jk > 0 ? f2 / jk : 0.0;
-            mu = mu * (t1)*t3;
-            const double d = fabs(mu - old);
+            return mu * (t1)*t3;
+        };
+        // The reference's loop is  while (err > 0.001) { sweep; err = sum over the 18 cells of |new - old| }  with err = 18 before
+        // the first sweep (:552-556).  Here sweep k + 1 is computed WHILE the error of sweep k is summed -- the sum is a chain of
+        // 18 dependent additions over broadcast lanes, a fifth of a sweep's latency, and the next sweep does not depend on it; when
+        // the error says stop, the sweep that ran ahead is dropped.  Same values, same number of sweeps counted.
+        double mu = sweep(1.0);
+        double d = fabs(mu - 1.0), err = 18.0;
+        int iter = 1;
+        for (;;) {
+            const double ahead = sweep(mu);
             err = 0.0;
 #pragma unroll
             for (int c = 0; c < 9; ++c) {                                 // err += |ca[c] - old|; err += |co[c] - old|, c = 0 .. 8
                 err += gt_bcast(d, c);
                 err += gt_bcast(d, 9 + c);
             }
+            if (!(err > 0.001) || iter >= GTEST_MAX_ITER) break;
+            d = fabs(ahead - mu);
+            mu = ahead;
+            ++iter;
         }
         // :648-683 -- every lane its cell's terms, lane-uniform sums in the reference's order
         double t1 = 0.0, term1 = 0.0, term2 = 0.0, t2 = 0.0;
