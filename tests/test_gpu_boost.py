@@ -94,9 +94,10 @@ def test_boost_measures_vs_oracle(oracle, n, m, p_missing):
             assert np.array_equal(np.sort(h2, order=["snp_a", "snp_b"]), np.sort(hits, order=["snp_a", "snp_b"]))
 
 
-@pytest.mark.parametrize("n", [70, 1000, 4097])
+@pytest.mark.parametrize("n", [33, 70, 1000, 4097, 300_001])
 def test_select_case_control_compaction(oracle, n):
-    """gw_table_download_selected == the reference's m_cases_controls rows."""
+    """gw_table_download_selected == the reference's m_cases_controls rows (compressed_genotype_table5.cpp:443-575), from one
+    word (n = 33: two) to rows whose compact form needs more than the default 48 KB of dynamic LDS (n = 300 001: 75 KB)."""
     m = 7
     rng = np.random.default_rng(n)
     ts = oracle.pack_codes(_codes(rng, m, n, 0.04), "stream")
