@@ -651,7 +651,7 @@ hipError_t launch_boost_valu(const BoostArgs &a, bool fast, bool pre, hipStream_
 // c_m / c_d as floats such that c_m - c_d >= c_lo and c_m + c_d >= c_hi.  c_m == 0 (no first level) for a cohort with
 // one group only.
 QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
-    QuadBound q{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    QuadBound q{};
     if (n_cases == 0 || n_cases >= n) return q;
     const float pf = (float)((double)n_cases / (double)n);
     if (!(pf > 0.0f && pf < 1.0f)) return q;
@@ -665,6 +665,7 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
     q.n48 = u * std::nextafter(48.0f * (float)n, INFINITY);
     q.n30 = u * std::nextafter(30.0f * (float)n, INFINITY);
     q.n1 = (float)((double)n * 1.4426950408889634);
+    q.n1t = (float)((double)n * 1.4426950408889634 * (double)n / (double)(n - n_cases));
     // tables with missing calls (boost_bound_quad9_f): the linear part of the quadratic is no constant there
     q.kx = (float)(-h1);
     q.ks = (float)(p * h1 - h0);
@@ -678,6 +679,16 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
         q.c_m = std::nextafter((float)std::max(c_lo, c_hi), INFINITY);
         q.k0 = std::nextafter((float)k0, INFINITY);
         q.c27 = u * (27.0f * q.c_m * 1.000001f);
+        // the sum as  sum x^2 / s  (gw_boost_dev.h): its constant / linear remainder with the float c and p actually used, in FP64,
+        // rounded up; the rounding of a sum of magnitude p X instead of q is the constant u 24 c n, added to the error
+        // bound's constant terms of both forms
+        const double cm = (double)q.c_m;
+        q.k0x = std::nextafter((float)(k0 - cm * (2.0 * p * (double)n_cases - p * p * (double)n)), INFINITY);
+        q.kx9 = std::nextafter((float)(-h1 - 2.0 * p * cm), INFINITY);
+        q.ks9 = std::nextafter((float)(p * h1 - h0 + cm * p * p), INFINITY);
+        q.cx = u * std::nextafter(24.0f * q.c_m * (float)n, INFINITY);
+        q.n48 += q.cx;
+        q.nk += q.cx;
         return q;
     }
     q.c_d = (float)(0.5 * (c_hi - c_lo));
@@ -698,7 +709,7 @@ hipError_t launch_boost(const BoostLaunch &l) {
     a.marf = l.d_marf; a.bound_threshold = l.bound_threshold; a.dense_err = l.dense_err ? 1 : 0;
     a.cct = l.matrix_cores ? l.d_cct : nullptr;
     a.lg_n = (float)(std::log2((double)(l.n_individs ? l.n_individs : 1u)) * 1.000001) + 1.0e-5f;
-    a.quad = QuadBound{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    a.quad = QuadBound{};
     a.fp4_scale[0] = 126; a.fp4_scale[1] = 127; a.fp4_scale[2] = 128;
     a.cand = l.candidates.records; a.cand_count = l.candidates.count; a.cand_cap = l.candidates.capacity;
     const bool fast = l.no_missing_call;

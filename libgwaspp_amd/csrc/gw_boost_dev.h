@@ -203,10 +203,24 @@ __device__ __forceinline__ float boost_bound_split(const uint32_t (&ca)[9], cons
 //   * the final sum and the factor 2 ln 2 with its roundings:  u (25 c q + 13 n + 16.1 n T) + 3.5 u |bound|
 //   err below uses (27, 48, 30, 6), the first three folded with u into QuadBound's constants on the host.  The screen checks  measure <= bound1 + err1  for every pair that gets its FP64
 //   measure (check_upper_bound in k_boost_finish), as it checks the second level.
+//
+// One curvature constant (TWO = false, balanced cohorts), later in round 4: the sum without d.  The x of a table without a missing
+// call add up to the case count X and the s to n, so  sum d^2 / s = sum x^2 / s - (2 p X - p^2 n)  and
+//   k0 + c sum d^2 / s = c sum x^2 / s + k0x,   k0x = k0 - c (2 p X - p^2 n)   (the host, in FP64 from the float p and c, rounded up)
+// -- per cell  t = x / s, qx = fma(x, t, qx)  and no  d = fma(-p, s, x): nine multiply-adds per pair less.  What it costs: qx ~ p X
+// where q ~ 10, so the rounding of the sum is no longer relative to q.  t: 3u relative (reciprocal 2u, product u); qx: 3u of the
+// term + u qx per step, nine steps: 12u qx, qx <= X;  A0 = fma(c, qx, k0x): 12u c X + u (c X + |k0x|), |k0x| <= 1.01 n + 2 c X:
+// u (15 c X + 1.01 n).  err replaces its  27u c q  by the constant  u 24 c n  (QuadBound::cx, X <= n, rounded up; 0.04 at n = 10^4
+// beside the 0.03 of u 48 n).  With tables that HAVE missing calls (boost_bound_quad9_f) X and S are the pair's own sums, which that
+// form computes anyway:  c sum d^2 / s - h(p) S - h'(p)(X - p S) = c sum x^2 / s + (kx - 2 p c) X + (ks + c p^2) S  =: ... kx9 X + ks9 S.
+#ifndef GW_QUAD_X2   // 0 (measurement only): the d form for one constant as well
+#define GW_QUAD_X2 1
+#endif
 struct QuadBound {
     float p, c_m, c_d, k0, c27;  // c27 = u 27 max(c_lo, c_hi), u = 2^-24; c_m == 0: no first level
+    float k0x, cx, kx9, ks9;     // one curvature constant: k0 - c (2 p X - p^2 n); u 24 c n; kx - 2 p c; ks + c p^2
     float n48, n30;              // u 48 n and u 30 n (rounded up): the error bound's constant terms
-    float n1;                    // N1 = n lg e
+    float n1, n1t;               // N1 = n lg e; N1 n / n_controls (tao - 1 from the cases' term alone)
     float kx, ks, nk, n22;       // tables with missing calls: -h'(p), p h'(p) - h(p); u n (10 (2 |h'(p)| + 1) + 26) and u 22 n, rounded up
 };
 // (fx, fs: a cell's case count and its total as floats -- exact, counts are below 2^24)
@@ -220,26 +234,36 @@ __device__ __forceinline__ float boost_bound_quad_f(const float (&fx)[9], const 
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
         const float x = fx[c], s = fs[c];
-        const float d = __builtin_fmaf(-qb.p, s, x);
-        const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
-        q_m = __builtin_fmaf(d, t, q_m);
-        if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
+        if constexpr (TWO || !GW_QUAD_X2) {
+            const float d = __builtin_fmaf(-qb.p, s, x);
+            const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
+            q_m = __builtin_fmaf(d, t, q_m);
+            if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
+        } else {  // sum x^2 / s; the constant part of sum d^2 / s is in k0x
+            const float t = gw_fmul_legacy(x, __builtin_amdgcn_rcpf(s));  // s == 0: x == 0 and 0 x inf = 0
+            q_m = __builtin_fmaf(x, t, q_m);
+        }
     }
     // tao - 1 = sum over the groups of  u'_0 (v'_0 S00 + v'_2 S02) + u'_2 (v'_0 S20 + v'_2 S22) - (n u_1) v_1
+    // -- and the controls' term is the cases' times P(case) / P(control): everyone is one or the other, so P(0) d_a0 + P(1) d_a1 = 0
+    // per genotype, i.e. u(controls) = -P(0) / P(1) u(cases), and v = P(c) e_bc / n gives v(controls) = -v(cases).  One group is
+    // evaluated, the factor 1 + P(0) / P(1) = n / n_controls is in QuadBound::n1t.  (The error bound's T <= ea eb stays: with
+    // rho = P(0) / P(1), (1 + rho) ea_0 eb_0 <= max(1, rho) ea_0 (2 eb_0) = ea eb.)
     float t1 = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < (GW_QUAD_X2 ? 1 : 2); ++g) {
         const float r0 = __builtin_fmaf(f2.vb[3 * g + 1], fs[2], f2.vb[3 * g] * fs[0]);
         const float r2 = __builtin_fmaf(f2.vb[3 * g + 1], fs[8], f2.vb[3 * g] * fs[6]);
         t1 = __builtin_fmaf(f1.ua[3 * g], r0, t1);
         t1 = __builtin_fmaf(f1.ua[3 * g + 1], r2, t1);
         t1 = __builtin_fmaf(-f1.ua[3 * g + 2], f2.vb[3 * g + 2], t1);
     }
-    const float A0 = __builtin_fmaf(qb.c_m, q_m, qb.k0);
+    const float A0 = __builtin_fmaf(qb.c_m, q_m, (TWO || !GW_QUAD_X2) ? qb.k0 : qb.k0x);
     const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
-    const float r = 1.3862943611198906f * __builtin_fmaf(qb.n1, t1, (A1 + f1.ki) + f2.kj);  // 2 ln 2
-    // (c27, n30, n48 arrive multiplied by u = 2^-24, exactly: a power of two)
-    err = __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48)));
+    const float r = 1.3862943611198906f * __builtin_fmaf(GW_QUAD_X2 ? qb.n1t : qb.n1, t1, (A1 + f1.ki) + f2.kj);  // 2 ln 2
+    // (c27, n30, n48, cx arrive multiplied by u = 2^-24, exactly: a power of two; one constant: cx is part of n48)
+    const float e0 = __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, f1.ea * f2.eb, qb.n48));
+    err = (TWO || !GW_QUAD_X2) ? __builtin_fmaf(qb.c27, q_m, e0) : e0;
     return r;
 }
 // The first level for tables WITH missing calls (all nine cells counted; the rows / columns of a pair's table no longer add up
@@ -272,10 +296,15 @@ __device__ __forceinline__ float boost_bound_quad9_f(const float (&fx)[9], const
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const float x = fx[3 * a + b], y = fy[3 * a + b], s = x + y;
-            const float d = __builtin_fmaf(-qb.p, s, x);
-            const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
-            q_m = __builtin_fmaf(d, t, q_m);
-            if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
+            if constexpr (TWO || !GW_QUAD_X2) {
+                const float d = __builtin_fmaf(-qb.p, s, x);
+                const float t = gw_fmul_legacy(d, __builtin_amdgcn_rcpf(s));  // s == 0: d == 0 and 0 x inf = 0
+                q_m = __builtin_fmaf(d, t, q_m);
+                if constexpr (TWO) q_d = __builtin_fmaf(fabsf(d), t, q_d);
+            } else {  // sum x^2 / s; the rest of sum d^2 / s is linear in the pair's totals: kx9, ks9
+                const float t = gw_fmul_legacy(x, __builtin_amdgcn_rcpf(s));
+                q_m = __builtin_fmaf(x, t, q_m);
+            }
             rx[a] += x; ry[a] += y; cx[b] += x; cy[b] += y;   // exact
             in_c = __builtin_fmaf(s, f2.rb[b], in_c);
             in_t = __builtin_fmaf(s, f2.rb[3 + b], in_t);
@@ -293,11 +322,12 @@ __device__ __forceinline__ float boost_bound_quad9_f(const float (&fx)[9], const
         k = __builtin_fmaf(cy[g], f2.lqb[3 + g], k);
     }
     const float t1 = tao - 1.0f;
-    const float lin = __builtin_fmaf(qb.kx, xs, qb.ks * ss);
+    const float lin = (TWO || !GW_QUAD_X2) ? __builtin_fmaf(qb.kx, xs, qb.ks * ss) : __builtin_fmaf(qb.kx9, xs, qb.ks9 * ss);
     const float A0 = __builtin_fmaf(qb.c_m, q_m, lin);
     const float A1 = TWO ? __builtin_fmaf(qb.c_d, q_d, A0) : A0;
     const float r = 1.3862943611198906f * __builtin_fmaf(qb.n1, t1, A1 + k);  // 2 ln 2
-    err = __builtin_fmaf(qb.c27, q_m, __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, fabsf(t1), __builtin_fmaf(qb.n22, f1.ma + f2.mb, qb.nk))));
+    const float e0 = __builtin_fmaf(3.5762787e-7f, fabsf(r), __builtin_fmaf(qb.n30, fabsf(t1), __builtin_fmaf(qb.n22, f1.ma + f2.mb, qb.nk)));
+    err = (TWO || !GW_QUAD_X2) ? __builtin_fmaf(qb.c27, q_m, e0) : e0;  // (one constant: the sum's rounding is the constant cx, part of nk)
     return r;
 }
 template <bool TWO = true>
