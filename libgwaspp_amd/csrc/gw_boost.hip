@@ -323,18 +323,39 @@ __global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint3
         // the first sweep (:552-556).  Here sweep k + 1 is computed WHILE the error of sweep k is summed -- the sum is a chain of
         // 18 dependent additions over broadcast lanes, a fifth of a sweep's latency, and the next sweep does not depend on it; when
         // the error says stop, the sweep that ran ahead is dropped.  Same values, same number of sweeps counted.
-        double mu = sweep(1.0);
-        double d = fabs(mu - 1.0), err = 18.0;
-        int iter = 1;
-        for (;;) {
-            const double ahead = sweep(mu);
-            err = 0.0;
+        // The error itself, in the reference's order, is a chain of 18 broadcasts and additions -- half of a sweep's instructions,
+        // and the sweeps of the slowest pair (27 000 at config 5) are the kernel's run time.  The loop only needs to know on which
+        // side of 0.001 it lies: the same 18 non-negative terms summed in FP32 by a shift-and-add tree (four v_add_f32 with a DPP
+        // row shift, the two row totals broadcast) differ from the ordered FP64 sum by less than 2e-6 of it (rounding of the
+        // terms to float 6e-8 each, of the sums 18 x 6e-8; a term too small for a float counts as 0, one too large as infinity), so
+        // outside a band of 2e-5 around the threshold the FP32 sum decides, and inside it -- or when it is a NaN -- the ordered sum does.
+        auto settled = [&](double d) -> bool {   // d = the lane's |new - old|; true <=> the reference's error sum is NOT > 0.001
+            float f = lane < 18 ? (float)d : 0.0f;
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x111, 0xf, 0xf, true));  // row_shr:1
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x112, 0xf, 0xf, true));  // row_shr:2
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x114, 0xf, 0xf, true));  // row_shr:4
+            f += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x118, 0xf, 0xf, true));  // row_shr:8
+            const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), 15)) +
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), 31));
+            if (total > 0.00100002f) return false;
+            if (total < 0.00099998f) return true;
+            asm volatile("" : "+v"(d));   // (keeps the ordered sum on this side of the branches: it has no side effect to hold it here)
+            double err = 0.0;
 #pragma unroll
             for (int c = 0; c < 9; ++c) {                                 // err += |ca[c] - old|; err += |co[c] - old|, c = 0 .. 8
                 err += gt_bcast(d, c);
                 err += gt_bcast(d, 9 + c);
             }
-            if (!(err > 0.001) || iter >= GTEST_MAX_ITER) break;
+            return !(err > 0.001);
+        };
+        double mu = sweep(1.0);
+        double d = fabs(mu - 1.0);
+        int iter = 1;
+        bool done;
+        for (;;) {
+            const double ahead = sweep(mu);
+            done = settled(d);
+            if (done || iter >= GTEST_MAX_ITER) break;
             d = fabs(ahead - mu);
             mu = ahead;
             ++iter;
@@ -357,7 +378,7 @@ __global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint3
             }
         }
         if (lane == 0) {
-            if (err > 0.001 && status) atomicAdd(&status[0], 1ull);
+            if (!done && status) atomicAdd(&status[0], 1ull);
             out[2 * p] = (im + log(tao)) * n_individs * 2.0;
             // allelic joint distribution and the odds-ratio z value, :686-701 (uint arithmetic, as the reference)
             uint32_t aj[8];
@@ -373,7 +394,11 @@ __global__ void __launch_bounds__(256) k_gtest(const uint32_t *tabs, const uint3
             const double v_aff = 1 / (double)aj[0] + 1 / (double)aj[1] + 1 / (double)aj[2] + 1 / (double)aj[3];
             const double or_unf = log((double)(aj[4] * aj[7]) / (double)(aj[5] * aj[6]));
             const double v_unf = 1 / (double)aj[4] + 1 / (double)aj[5] + 1 / (double)aj[6] + 1 / (double)aj[7];
+#ifdef GW_GTEST_COUNT_SWEEPS   // measurement only (tools/build_variant_file.sh): the sweeps a pair took, in place of its z value
+            out[2 * p + 1] = (double)iter;
+#else
             out[2 * p + 1] = (or_aff - or_unf) / sqrt(v_aff + v_unf);
+#endif
         }
     }
 }
