@@ -1,5 +1,11 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""How many proportional-fitting sweeps does BOOST stage 2 (k_gtest, computeGTest epistasis_func.cpp:508-704) take per pair on
+config 5's hits?  Needs the variant build that returns the sweep count in place of the z value:
+    tools/build_variant_file.sh sweeps gw_boost.hip -DGW_GTEST_COUNT_SWEEPS
+    GW_LIBGWSCAN=libgwaspp_amd/exp/libgwscan_sweeps.so python3 tools/gtest_sweeps_probe.py
+(round 4, MI355X: median 4, 90 % under 3 008, max 27 312 of 22 096 pairs -- the kernel's time is the slowest pair's chain)"""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import libgwaspp_amd as gw
 from libgwaspp_amd import capi
 n, m = 10000, 100000
