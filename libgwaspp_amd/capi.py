@@ -37,6 +37,7 @@ OPT_BOOST_LUT = 17          # retired (round 4)
 OPT_BOOST_FP4 = 18
 OPT_BOOST_FIRST_LEVEL = 19
 OPT_BOOST_CANDIDATES = 20
+OPT_BOOST_ROWS_PER_LAUNCH = 21
 
 
 class GwError(RuntimeError):

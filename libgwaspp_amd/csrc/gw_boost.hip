@@ -726,6 +726,19 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
 
 hipError_t launch_boost(const BoostLaunch &l) {
     if (l.n_a == 0 || l.n_b == 0) return hipSuccess;
+    // a screen whose candidates would not fit the list even at its cap (all pairs of more than ~400 000 SNPs in one call): row
+    // block by row block through the same list -- hits, tally and the lost-candidates count accumulate across the launches
+    if (l.prefilter && !l.d_dense && l.candidates.records && l.candidates.rows_per_launch && l.n_a > l.candidates.rows_per_launch) {
+        for (uint32_t r0 = 0; r0 < l.n_a; r0 += l.candidates.rows_per_launch) {
+            BoostLaunch part = l;
+            part.a_begin = l.a_begin + r0;
+            part.n_a = std::min(l.candidates.rows_per_launch, l.n_a - r0);
+            part.candidates.rows_per_launch = 0;
+            const hipError_t e = launch_boost(part);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     BoostArgs a;
     a.cc = l.d_cc; a.cc_stride_w = l.cc_stride_w; a.wc = l.wc; a.wt = l.wt; a.mar = l.d_mar; a.frac = l.d_frac; a.xlogx = l.d_xlogx;
     a.a_begin = l.a_begin; a.n_a = l.n_a; a.b_begin = l.b_begin; a.n_b = l.n_b;

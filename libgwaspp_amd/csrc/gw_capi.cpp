@@ -101,6 +101,7 @@ struct gw_table {
     // kernel shape
     int opt_unroll = 0, opt_mask_lds = -1, opt_blocks_per_cu = 0, opt_nt = 1, opt_threads = 0, opt_pipeline = -1, opt_complement = 1, opt_prefilter = 1, opt_boost_mfma = 1, opt_short_rows = 1, opt_segment = 0, opt_prefilter_selftest = 0, opt_reserve_cus = 0, opt_defer = -1, opt_boost_fp4 = 1, opt_boost_first_level = 1;
     long long opt_boost_candidates = 0;  // records the candidate list may hold; 0 = auto (from the size of the block pair)
+    long long opt_boost_rows = 0;        // rows of a block pair per launch of the pre-filtered screen; 0 = auto (whole, unless the list's cap says otherwise)
     char last_boost_kernel[96] = "";  // ... and the last pair screen (gw_last_boost_kernel)
     char last_scan_kernel[96] = "";  // instantiation the last case/control scan launched (gw_last_scan_kernel)
     uint32_t *d_raw = nullptr;  // [row][6] partial sums of a column-segmented scan
@@ -998,13 +999,21 @@ bool boost_prefilter_on(const gw_table *t) { return t->opt_prefilter != 0 && t->
 // the candidate list of a screen over `pairs_upper` pairs at most: grow-only, owned by the handle.  Auto size: one
 // record per 64 pairs + 65 536 but at least 2^20, at most one per pair and 32 M records (the logarithm-free first level lets ~3 pairs in 10 000 through
 // on unlinked SNPs; a block that overflows it is repeated with every pair in FP64, so the size only bounds the cost)
-int boost_candidates(gw_table *t, unsigned long long pairs_upper, gw::BoostCandidateList *out) {
+int boost_candidates(gw_table *t, uint64_t n_a, uint64_t n_b, gw::BoostCandidateList *out) {
     const size_t rec = gw::boost_candidate_bytes(t->any_missing);
+    const unsigned long long pairs_upper = (unsigned long long)n_a * n_b, cap = 32ull << 20;
     // (a block pair of up to 2^20 pairs gets a record per pair: whatever the threshold, it cannot overflow)
     unsigned long long want = t->opt_boost_candidates > 0
                                   ? (unsigned long long)t->opt_boost_candidates
                                   : std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper / 64u + 65536u, 1ull << 20),
-                                                                 std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper, 1ull), 32ull << 20));
+                                                                 std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper, 1ull), cap));
+    // a block pair whose record-per-64-pairs allowance exceeds the cap (all pairs of ~450 000 SNPs and more in one call) is
+    // screened in row blocks that keep the allowance: (cap - 65 536) x 64 / n_b rows, a multiple of the 128-row tile
+    out->rows_per_launch = 0;
+    if (t->opt_boost_rows > 0)
+        out->rows_per_launch = (uint32_t)std::min<long long>(((t->opt_boost_rows + 127) / 128) * 128, 1ll << 30);
+    else if (t->opt_boost_candidates <= 0 && pairs_upper / 64u + 65536u > cap && n_b)
+        out->rows_per_launch = (uint32_t)std::max<unsigned long long>(128ull, (((cap - 65536ull) * 64ull) / n_b) & ~127ull);
     const size_t need = (size_t)want * rec;
     if (need > t->cand_bytes) {
         if (t->d_cand) GW_HIP(hipFree(t->d_cand));
@@ -1088,7 +1097,7 @@ int boost_common(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t b_begin, 
     l.bound_threshold = bound_thr;
     l.dense_err = t->opt_prefilter == 3 || t->opt_prefilter == 5;
     l.first_level = diag ? t->opt_prefilter >= 4 : t->opt_boost_first_level != 0;
-    if (pre && !dense && (rc = boost_candidates(t, (unsigned long long)n_a * n_b, &l.candidates))) return rc;
+    if (pre && !dense && (rc = boost_candidates(t, n_a, n_b, &l.candidates))) return rc;
     auto launch = [&](bool prefilter) {
         l.prefilter = prefilter;
         return gw::launch_boost(l);
@@ -1181,7 +1190,7 @@ int gw_boost_screen_device(gw_table *t, uint64_t a_begin, uint64_t n_a, uint64_t
     l.d_hits = reinterpret_cast<gw::BoostHit *>(static_cast<char *>(d_list) + GW_BOOST_LIST_HEADER_BYTES);
     l.max_hits = capacity;
     l.prefilter = pre; l.bound_threshold = bound_thr; l.first_level = t->opt_boost_first_level != 0;
-    if (pre && (rc = boost_candidates(t, (unsigned long long)n_a * n_b, &l.candidates))) return rc;
+    if (pre && (rc = boost_candidates(t, n_a, n_b, &l.candidates))) return rc;
     GW_HIP(gw::launch_boost(l));
     return GW_OK;
 }
@@ -1486,6 +1495,10 @@ int gw_set_option(gw_table *t, int option, int64_t v) {
         if (v < 0 || v > (1ll << 28)) return fail(GW_E_INVALID, "boost_candidates must be 0 (auto) or a record count up to 2^28");
         t->opt_boost_candidates = v;
         return GW_OK;
+    case GW_OPT_BOOST_ROWS_PER_LAUNCH:
+        if (v < 0 || v > (1ll << 30)) return fail(GW_E_INVALID, "boost_rows_per_launch must be 0 (auto) or a row count up to 2^30");
+        t->opt_boost_rows = v;
+        return GW_OK;
     case GW_OPT_DEFER_RECORDS:
         if (v < -1 || v > 1) return fail(GW_E_INVALID, "defer_records must be -1 (auto), 0 or 1");
         t->opt_defer = (int)v;
@@ -1531,6 +1544,7 @@ int gw_get_option(gw_table *t, int option, int64_t *v) {
     case GW_OPT_BOOST_STAGGER_US: *v = 0; return GW_OK;  // retired (round 4)
     case GW_OPT_BOOST_LUT: *v = 0; return GW_OK;         // retired (round 4)
     case GW_OPT_BOOST_CANDIDATES: *v = t->opt_boost_candidates; return GW_OK;
+    case GW_OPT_BOOST_ROWS_PER_LAUNCH: *v = t->opt_boost_rows; return GW_OK;
     case GW_OPT_BOOST_FP4: *v = t->opt_boost_fp4; return GW_OK;
     case GW_OPT_BOOST_FIRST_LEVEL: *v = t->opt_boost_first_level; return GW_OK;
     case GW_OPT_COLUMN_SEGMENT: *v = column_segment(t); return GW_OK;

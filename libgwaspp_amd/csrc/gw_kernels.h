@@ -145,6 +145,9 @@ struct BoostCandidateList {
     uint32_t *records = nullptr;
     unsigned long long *count = nullptr;
     unsigned long long capacity = 0;   // in records of the kernel's own size
+    // a block pair too large for the list at its cap is screened in row blocks of this many rows (a multiple of 128; 0 = one
+    // launch): counter zeroed, counting kernel, k_boost_finish per row block, all on the launch's stream
+    uint32_t rows_per_launch = 0;
 };
 inline size_t boost_candidate_bytes(bool nine_cells) { return (2u + 2u * (nine_cells ? 9u : 4u)) * sizeof(uint32_t); }
 

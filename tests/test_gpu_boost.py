@@ -445,6 +445,43 @@ def test_block_calls_on_fp4_equal_the_int8_kernels(n, m):
         assert t.last_boost_kernel() == "gw::k_boost_mfma_fp4<true, 3, 1, 0, false>"
 
 
+@pytest.mark.parametrize("missing", [0, 655])
+def test_screen_in_row_blocks_equals_one_launch(missing):
+    """GW_OPT_BOOST_ROWS_PER_LAUNCH: the pre-filtered screen of a block pair row block by row block through one candidate
+    list (what a call over all pairs of ~450 000 SNPs and more does by itself, because its candidate allowance exceeds the
+    list's cap) -- same hits, same tallies, host form and device form, whole triangle and an off-diagonal block."""
+    n, m = 2500, 700
+    with gw.GwTable(n, m) as t:
+        t.simulate(23, 0, missing)
+        t.simulate_phenotype(23)
+        thr = 12.0 if missing == 0 else -1.0e9      # (with missing calls the measures of unlinked pairs are negative: every pair)
+        for (a, na, b, nb) in ((0, m, 0, m), (37, 500, 300, 400)):
+            t.set_option(gw.capi.OPT_BOOST_ROWS_PER_LAUNCH, 0)
+            want, wh, wp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, max_hits=1 << 18, extremes=False)
+            assert wh > 20
+            for rows in (1, 128, 300):          # rounded up to 128, 128, 384
+                t.set_option(gw.capi.OPT_BOOST_ROWS_PER_LAUNCH, rows)
+                got, gh, gp, _, _ = t.boost_screen(a, na, b, nb, threshold=thr, max_hits=1 << 18, extremes=False)
+                assert (gh, gp) == (wh, wp)
+                assert np.array_equal(np.sort(got, order=["snp_a", "snp_b"]), np.sort(want, order=["snp_a", "snp_b"]))
+        # the device form, list in HBM
+        cap = 1 << 18
+        lst = gw.capi.DeviceBuffer(gw.capi.BOOST_LIST_HEADER_BYTES + 16 * cap)
+        lists = []
+        st = t.stream()
+        for rows in (0, 128):
+            t.set_option(gw.capi.OPT_BOOST_ROWS_PER_LAUNCH, rows)
+            t.boost_list_init(lst.ptr, st)
+            t.boost_screen_device(0, m, 0, m, lst.ptr, cap, thr, st)
+            hits, n_hits, n_pairs, aux0 = gw.parse_boost_list(lst.download(st), cap)
+            lists.append((np.sort(hits, order=["snp_a", "snp_b"]), n_hits, n_pairs, aux0))
+        assert lists[0][1:] == lists[1][1:] and np.array_equal(lists[0][0], lists[1][0]) and lists[0][3] == 0
+        t.set_option(gw.capi.OPT_BOOST_ROWS_PER_LAUNCH, 0)
+        assert t.get_option(gw.capi.OPT_BOOST_PREFILTER_TRIPS) == 0
+        with pytest.raises(gw.GwError):
+            t.set_option(gw.capi.OPT_BOOST_ROWS_PER_LAUNCH, -1)
+
+
 def test_candidate_list_overflow_repeats_the_block_in_fp64():
     """GW_OPT_BOOST_CANDIDATES: a candidate list too small for what the in-kernel bound lets through is reported through
     the tally (like a violated error model) and the block is repeated with every pair in FP64 -- same hits, one trip."""
