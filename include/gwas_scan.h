@@ -432,9 +432,9 @@ typedef enum gw_option {
     GW_OPT_BOOST_ROWS_PER_LAUNCH = 21, /* pre-filtered pair screen: a block pair [a, a + n_a) x [b, b + n_b) is screened
                                 n rows of its first range at a time (rounded up to a multiple of 128), every row block
                                 through the same candidate list, hits and tallies accumulating -- same results as one launch.
-                                0 (default) auto = one launch, unless the automatic candidate allowance of the block pair
-                                exceeds the list's cap of 32 M records (all pairs of ~450 000 SNPs and more in one call):
-                                then (32 M - 65 536) x 64 / n_b rows per launch, which keeps the allowance */
+                                0 (default) auto = one launch, unless the list's cap of 32 M records would leave the block pair
+                                less than a record per 512 pairs (n_a x n_b > 1.7e10: all pairs of ~130 000 SNPs and more in
+                                one call): then (32 M - 65 536) x 64 / n_b rows per launch, a record per 64 pairs again */
     GW_OPT_DEFER_RECORDS = 15, /* rows up to ~100 k samples: 1 = nothing is written while the table is being read; a wave
                                 parks the six sums of its finished rows in LDS and, after its last row, runs the FP64
                                 epilogue over all of them and writes its records in one burst (launches are cut

@@ -726,7 +726,7 @@ QuadBound quad_bound_constants(uint32_t n_cases, uint32_t n) {
 
 hipError_t launch_boost(const BoostLaunch &l) {
     if (l.n_a == 0 || l.n_b == 0) return hipSuccess;
-    // a screen whose candidates would not fit the list even at its cap (all pairs of more than ~400 000 SNPs in one call): row
+    // a screen whose candidates might not fit the list even at its cap (all pairs of more than ~130 000 SNPs in one call): row
     // block by row block through the same list -- hits, tally and the lost-candidates count accumulate across the launches
     if (l.prefilter && !l.d_dense && l.candidates.records && l.candidates.rows_per_launch && l.n_a > l.candidates.rows_per_launch) {
         for (uint32_t r0 = 0; r0 < l.n_a; r0 += l.candidates.rows_per_launch) {

@@ -1007,12 +1007,13 @@ int boost_candidates(gw_table *t, uint64_t n_a, uint64_t n_b, gw::BoostCandidate
                                   ? (unsigned long long)t->opt_boost_candidates
                                   : std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper / 64u + 65536u, 1ull << 20),
                                                                  std::min<unsigned long long>(std::max<unsigned long long>(pairs_upper, 1ull), cap));
-    // a block pair whose record-per-64-pairs allowance exceeds the cap (all pairs of ~450 000 SNPs and more in one call) is
-    // screened in row blocks that keep the allowance: (cap - 65 536) x 64 / n_b rows, a multiple of the 128-row tile
+    // a block pair that would be left with less than a record per 512 pairs at the cap (n_a x n_b > 1.7e10: all pairs of ~130 000
+    // SNPs and more in one call; the first level lets ~1 pair in 3 300 through) is screened in row blocks that have the full
+    // record-per-64-pairs allowance: (cap - 65 536) x 64 / n_b rows, a multiple of the 128-row tile
     out->rows_per_launch = 0;
     if (t->opt_boost_rows > 0)
         out->rows_per_launch = (uint32_t)std::min<long long>(((t->opt_boost_rows + 127) / 128) * 128, 1ll << 30);
-    else if (t->opt_boost_candidates <= 0 && pairs_upper / 64u + 65536u > cap && n_b)
+    else if (t->opt_boost_candidates <= 0 && pairs_upper / 512u + 65536u > cap && n_b)
         out->rows_per_launch = (uint32_t)std::max<unsigned long long>(128ull, (((cap - 65536ull) * 64ull) / n_b) & ~127ull);
     const size_t need = (size_t)want * rec;
     if (need > t->cand_bytes) {

@@ -448,8 +448,8 @@ def test_block_calls_on_fp4_equal_the_int8_kernels(n, m):
 @pytest.mark.parametrize("missing", [0, 655])
 def test_screen_in_row_blocks_equals_one_launch(missing):
     """GW_OPT_BOOST_ROWS_PER_LAUNCH: the pre-filtered screen of a block pair row block by row block through one candidate
-    list (what a call over all pairs of ~450 000 SNPs and more does by itself, because its candidate allowance exceeds the
-    list's cap) -- same hits, same tallies, host form and device form, whole triangle and an off-diagonal block."""
+    list (what a call over all pairs of ~130 000 SNPs and more does by itself, because the list's cap would leave it less
+    than a record per 512 pairs) -- same hits, same tallies, host form and device form, whole triangle and an off-diagonal block."""
     n, m = 2500, 700
     with gw.GwTable(n, m) as t:
         t.simulate(23, 0, missing)
