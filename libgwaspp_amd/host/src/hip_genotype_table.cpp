@@ -515,7 +515,7 @@ void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::
     settle();
     if (!installed) std::abort();
     passing.clear();
-    std::vector<gw_boost_hit> hits(1u << 16);
+    std::vector<gw_boost_hit> hits(1u << 20);   // (16 MB; a list that turns out too short costs a second screen)
     uint64_t n_hits = 0;
     for (;;) {
         die_unless_ok(gw_boost_screen(tbl, 0, (uint64_t)max_row, 0, (uint64_t)max_row, threshold, hits.data(), hits.size(),
