@@ -2,6 +2,7 @@
 #include "genetics/genotype/hip_genotype_table.h"
 
 #include <algorithm>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -515,21 +516,28 @@ void HipGenotypeTable::boostScreen(double threshold, std::vector<std::pair<std::
     settle();
     if (!installed) std::abort();
     passing.clear();
-    std::vector<gw_boost_hit> hits(1u << 20);   // (16 MB; a list that turns out too short costs a second screen)
+    // (2^20 records = 16 MB, not value-initialised: only what a screen delivers is ever touched; a list that turns out too
+    // short costs a second screen)
+    size_t room = (size_t)1u << 20;
+    std::unique_ptr<gw_boost_hit[]> buf(new gw_boost_hit[room]);
     uint64_t n_hits = 0;
     for (;;) {
-        die_unless_ok(gw_boost_screen(tbl, 0, (uint64_t)max_row, 0, (uint64_t)max_row, threshold, hits.data(), hits.size(),
+        die_unless_ok(gw_boost_screen(tbl, 0, (uint64_t)max_row, 0, (uint64_t)max_row, threshold, buf.get(), room,
                                       &n_hits, nullptr, nullptr, nullptr),
                       "gw_boost_screen");
-        if (n_hits <= hits.size()) break;
-        hits.resize(n_hits);  // the list was capped: run again with room for all of it
+        if (n_hits <= room) break;
+        room = (size_t)n_hits;  // the list was capped: run again with room for all of it
+        buf.reset(new gw_boost_hit[room]);
     }
-    hits.resize(n_hits);
-    std::sort(hits.begin(), hits.end(), [](const gw_boost_hit &a, const gw_boost_hit &b) {
+    gw_boost_hit *const hits_begin = buf.get(), *const hits_end = buf.get() + n_hits;
+    std::sort(hits_begin, hits_end, [](const gw_boost_hit &a, const gw_boost_hit &b) {
         return a.snp_a != b.snp_a ? a.snp_a < b.snp_a : a.snp_b < b.snp_b;
     });
-    for (const gw_boost_hit &h : hits)
+    passing.reserve((size_t)n_hits);
+    for (const gw_boost_hit *ph = hits_begin; ph != hits_end; ++ph) {
+        const gw_boost_hit &h = *ph;
         passing.push_back(std::make_pair(std::make_pair((uint)h.snp_a, (uint)h.snp_b), h.measure));
+    }
 }
 
 void HipGenotypeTable::boostGTest(std::vector<std::pair<std::pair<uint, uint>, double> > &pairs, std::vector<double> &zval) {
