@@ -12,6 +12,9 @@
 //   bit 8  the refills as dwordx2 loads (twice as many instructions, the same bytes)
 //   bit 9  with bit 7: the B row comes from LDS (ds_read_b128 of a static buffer) instead of global memory -- what sharing
 //          operand rows between the waves of a workgroup through LDS would turn a third of the refills into
+//   bit 10 the B operands' expansion SHARED between the two waves of a workgroup that use the same B rows: a wave expands one
+//          of the pair's two chunks (4 instead of 8 v_bitop3 per sample group), writes it to LDS (ds_write_b128), barrier, and
+//          reads its partner's (ds_read_b128) -- not software-pipelined: the exchange sits in front of the group's MFMAs
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/mfma_loop_probe tools/mfma_loop_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -32,7 +35,8 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, int rounds, int sc_half, int sc_one, int sc_two,
                                                 uint32_t chunk_mask) {
-    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16, SADDR = MODE & 32, ONLY_B = MODE & 64, ONLY_A = MODE & 128, X2 = MODE & 256, B_LDS = MODE & 512;
+    constexpr bool FEED = MODE & 1, SHIFT = MODE & 2, LOADS = MODE & 4, SCHED = MODE & 8, VMASK = MODE & 16, SADDR = MODE & 32, ONLY_B = MODE & 64, ONLY_A = MODE & 128, X2 = MODE & 256, B_LDS = MODE & 512, B_SHARE = MODE & 1024;
+    __shared__ u32x4 s_share[B_SHARE ? 2 * 2 * 2 * 64 : 1];  // [parity][wx][wy][lane]
     __shared__ u32x4 s_b[B_LDS ? 256 * 4 : 1];
     if (B_LDS) { for (int k = 0; k < 4; ++k) s_b[k * 256 + threadIdx.x] = tbl[k * 256 + threadIdx.x]; __syncthreads(); }
     constexpr int TA = 2, NV = 2, NP = 4, NT = 8, RING = 4;
@@ -81,8 +85,21 @@ __global__ void __launch_bounds__(256, 2) k_loop(const u32x4 *tbl, float *out, i
                     xa[ta][c] = i32x8{(int)(cls(wa0[ta], c, 0) & mask), (int)(cls(wa0[ta], c, 1) & mask),
                                       (int)(cls(wa1[ta], c, 0) & mask), (int)(cls(wa1[ta], c, 1) & mask), 0, 0, 0, 0};
                 }
-                yb[c] = i32x8{(int)(cls(wb0, c, 0) & mask), (int)(cls(wb0, c, 1) & mask), (int)(cls(wb1, c, 0) & mask),
-                              (int)(cls(wb1, c, 1) & mask), 0, 0, 0, 0};
+                if (!B_SHARE)
+                    yb[c] = i32x8{(int)(cls(wb0, c, 0) & mask), (int)(cls(wb0, c, 1) & mask), (int)(cls(wb1, c, 0) & mask),
+                                  (int)(cls(wb1, c, 1) & mask), 0, 0, 0, 0};
+            }
+            if (B_SHARE) {
+                const uint32_t wy = wave >> 1, wx = wave & 1u;
+                const u32x4 mine_raw = wy ? wb1 : wb0;   // (four v_cndmask per sample group here; a real kernel would branch once per wave)
+                const u32x4 own = u32x4{cls(mine_raw, 0, 0) & mask, cls(mine_raw, 0, 1) & mask, cls(mine_raw, 1, 0) & mask, cls(mine_raw, 1, 1) & mask};
+                u32x4 *slot = s_share + ((k & 1) * 4) * 64;
+                slot[(wx * 2 + wy) * 64 + lane] = own;
+                __syncthreads();
+                const u32x4 oth = slot[(wx * 2 + (wy ^ 1u)) * 64 + lane];
+                // (the order of the four dwords along K is the same for every wave's A operands: chunk of wy first)
+                yb[0] = i32x8{(int)own[0], (int)own[1], (int)oth[0], (int)oth[1], 0, 0, 0, 0};
+                yb[1] = i32x8{(int)own[2], (int)own[3], (int)oth[2], (int)oth[3], 0, 0, 0, 0};
             }
             if (!FEED) {  // the expansion results are kept alive through one more instruction each... no: folded into `sink` at the end of the step
                 uint32_t s2 = 0;
@@ -184,6 +201,8 @@ int main() {
         run<7 + 128>("the kernel's loop without the pattern, 4 of the 6 refills", dtbl, dout, w, cus);
         run<7 + 256>("the kernel's loop without the pattern, refills as 12 dwordx2 loads", dtbl, dout, w, cus);
         run<7 + 128 + 512>("the kernel's loop without the pattern, 4 of the 6 refills + the B row from LDS", dtbl, dout, w, cus);
+        run<7 + 1024>("the kernel's loop without the pattern, B expansion shared through LDS", dtbl, dout, w, cus);
+        run<5 + 1024>("  ... and without the sign-bit shifts", dtbl, dout, w, cus);
     }
     return 0;
 }
